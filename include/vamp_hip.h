@@ -1,0 +1,145 @@
+/* vamp_hip.h -- C ABI of libvamp_hip.so, the MI355X (gfx950) implementation of VAMP's MCMC hot
+ * path: per-walker log-posterior (Voigt/Gaussian optical depth -> flux = exp(-tau) -> Gaussian
+ * chi^2 + priors) and the affine-invariant stretch move.
+ *
+ * The reference (sarahappleby/VAMP, pure Python) has no FFI/plugin interface; the boundary this
+ * library sits behind is the Python surface of class VPfit (vamp_1.0/vpfits.py:33).  Each entry
+ * point below names the reference code it replaces.  The Python side binds these with ctypes
+ * (vamp_amd/_lib.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative vamp_status; the message is available
+ *     from vamp_last_error() (thread-local storage owned by the library, valid until the next
+ *     failing call on that thread).  Nothing aborts or throws across the ABI.
+ *   - all host buffers are caller-owned, contiguous, C order; floating point is double and
+ *     indices are int32/int64 regardless of the device arithmetic type.  The library copies in
+ *     on set/init and out on run/get.  A vamp_ctx owns its device memory, stream and RNG state.
+ *   - a vamp_ctx is not thread-safe; use one per device.  ctypes releases the GIL during calls.
+ *   - non-finite parameters give that walker lnprob = -inf (vpfits.py:241-242 convention), not
+ *     an error.
+ */
+#ifndef VAMP_HIP_H
+#define VAMP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vamp_ctx vamp_ctx;
+
+enum vamp_status {
+    VAMP_OK = 0,
+    VAMP_ERR_ARG = -1,      /* bad argument */
+    VAMP_ERR_HIP = -2,      /* HIP runtime error */
+    VAMP_ERR_COMM = -3,     /* reserved (collectives are driven by the host through torch.distributed) */
+    VAMP_ERR_NOMEM = -4,    /* out of device or host memory */
+    VAMP_ERR_STATE = -5     /* not initialised / wrong call order */
+};
+
+/* parameterisation of one component */
+enum vamp_mode {
+    VAMP_GAUSS3 = 0,  /* (amplitude, centroid, sigma)            vpfits.py:219-262 */
+    VAMP_VOIGT4 = 1,  /* (amplitude, centroid, L_fwhm, G_fwhm)   vpfits.py:265-307 */
+    VAMP_NBZ3 = 2     /* (N, b, z) through physics.py:6-27,116-134; Lorentzian FWHM fixed */
+};
+
+enum vamp_dtype { VAMP_F64 = 0, VAMP_F32 = 1 };          /* per-pixel arithmetic type */
+enum vamp_wofz { VAMP_WOFZ_ACCURATE = 0, VAMP_WOFZ_HUMLICEK_W4 = 1 };
+
+#define VAMP_MAX_COMPONENTS 16
+#define VAMP_ABI_VERSION 1
+
+/* library identification */
+int vamp_version(void);
+const char* vamp_last_error(void);
+int vamp_device_count(int* n);
+
+/* context = one device + one stream.  dtype/wofz_kind choose the per-pixel arithmetic:
+ * (VAMP_F64, VAMP_WOFZ_ACCURATE) is the parity path; (VAMP_F32, VAMP_WOFZ_HUMLICEK_W4) the
+ * throughput path of BASELINE.json config 5.  Walker state is always double. */
+int vamp_ctx_create(vamp_ctx** out, int device, int dtype, int wofz_kind);
+int vamp_ctx_destroy(vamp_ctx* ctx);
+/* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the ctx's own */
+int vamp_ctx_set_stream(vamp_ctx* ctx, void* hip_stream);
+int vamp_ctx_synchronize(vamp_ctx* ctx);
+
+/* Upload the data of n_regions independent absorption regions (replaces
+ * VPfit.initialise_model's capture of frequency/flux/noise, vpfits.py:310-349, and the prior
+ * bounds of vpfits.py:249-252,292-297,320,326).
+ *   pix_off[n_regions+1]  CSR offsets into x/flux/noise
+ *   x                     abscissa (ascending inside a region; same units as the width params)
+ *   n_comp[n_regions]     components per region (<= VAMP_MAX_COMPONENTS)
+ *   mode                  vamp_mode, one for all regions
+ *   sample_sd             1 = reference likelihood with free precision sd~U(0,1) as the last
+ *                         dimension (vpfits.py:39,341); 0 = known per-pixel noise, -chi^2/2
+ *   include_norm          add -1/2 sum log(2 pi sigma_i^2) (vamp_2.0/vamp_src/fit/fit.py:156)
+ *   bounds[n_regions*4]   {c_lo, c_hi, sigma_max, fwhm_max} per region, or NULL to derive them
+ *                         from x as vpfits.py:250,320,326 do
+ *   nbz[n_regions*4]      {l_fixed, line[A], x_origin[Hz], x_scale[Hz]} for VAMP_NBZ3, else NULL */
+int vamp_set_regions(vamp_ctx* ctx, int n_regions, const int64_t* pix_off, const double* x,
+                     const double* flux, const double* noise, const int32_t* n_comp, int mode,
+                     int sample_sd, int include_norm, const double* bounds, const double* nbz);
+
+/* number of sampled dimensions of a region (q*K, +1 with sample_sd) */
+int vamp_region_ndim(vamp_ctx* ctx, int region, int* ndim);
+
+/* Log-posterior of W parameter vectors theta[W, D] for one region: replaces one PyMC
+ * evaluation of the model graph (profile closures vpfits.py:254-260/299-305, total :334-336,
+ * obs :341, priors :239-252/283-297).  chi2 may be NULL; with sample_sd it receives the
+ * unweighted sum of squared residuals. */
+int vamp_lnprob(vamp_ctx* ctx, int region, int64_t W, const double* theta, double* lnprob,
+                double* chi2);
+
+/* Per-component optical depths tau_comp[K, P] and model flux[P] for one parameter vector:
+ * the `component_k` and `profile` deterministics (vpfits.py:254-260, 299-305, 334-336) whose
+ * .value the callers read (vpspectrum.py:335,352-363).  Either output may be NULL. */
+int vamp_model(vamp_ctx* ctx, int region, const double* theta1, double* tau_comp,
+               double* flux_model);
+
+/* Device evaluation of Re w(x + i y) with the ctx's wofz_kind (test hook for the in-register
+ * Faddeeva evaluator; the profile of vpfits.py:57-76 is built on it). */
+int vamp_wofz_re(vamp_ctx* ctx, int64_t n, const double* x, const double* y, double* re_w);
+
+/* ---- ensemble sampler: replaces VPfit.mcmc_fit / the MCMC calls of find_bic
+ *      (vpfits.py:361-395, 420-425) with the stretch move of SURVEY Appendix B. ----
+ * Every region of the ctx gets W walkers (W even, W % split_block == 0, split_block even).
+ * theta0 is the concatenation over regions of [W, D_r] blocks.  Red/blue membership is a keyed
+ * permutation inside chunks of split_block consecutive walkers, re-drawn every step; all draws
+ * are Philox4x32-10 keyed by (seed, step, half, global walker id), so a trajectory does not
+ * depend on how walkers are sharded over devices. */
+int vamp_sampler_init(vamp_ctx* ctx, int64_t W, const double* theta0, uint64_t seed, double a,
+                      int32_t split_block);
+/* Restrict this ctx to shard `rank` of `world` equal shards of every half-step's active slots
+ * (walker-parallel runs of ONE region over several devices).  After each half-step the host
+ * all-gathers the walker rows [own_begin, own_end) of the state (RCCL via torch.distributed). */
+int vamp_sampler_set_shard(vamp_ctx* ctx, int rank, int world, int64_t* own_begin, int64_t* own_end);
+/* Use caller-owned device memory for the walker state (X[total_theta] and lnp[total_walkers],
+ * both double), e.g. torch tensors that take part in collectives.  Call before sampler_init. */
+int vamp_sampler_bind_state(vamp_ctx* ctx, void* X_dev, void* lnp_dev);
+int vamp_sampler_state_ptrs(vamp_ctx* ctx, void** X_dev, void** lnp_dev, int64_t* total_theta,
+                            int64_t* total_walkers);
+/* one half-step (half = 0 red moves, 1 blue moves), asynchronous on the ctx stream; the step
+ * counter advances after half 1 */
+int vamp_sampler_half_step(vamp_ctx* ctx, int half);
+/* same with every draw supplied by the host (deterministic-parity hook, single region):
+ * active_idx[n], partner_idx[n] walker ids, zz[n] stretch factors, logu[n] = log(u2) */
+int vamp_sampler_half_step_ext(vamp_ctx* ctx, int region, int64_t n, const int32_t* active_idx,
+                               const int32_t* partner_idx, const double* zz, const double* logu);
+/* n_steps full steps, keeping every thin-th sample.  chain[n_keep, total_theta],
+ * lnprob_chain[n_keep, total_walkers], n_accept[total_walkers] (accepted proposals so far) may
+ * be NULL.  seconds receives the wall time of the sampling loop (device-synchronised). */
+int vamp_sampler_run(vamp_ctx* ctx, int64_t n_steps, int thin, double* chain, double* lnprob_chain,
+                     int64_t* n_accept, double* seconds);
+int vamp_sampler_get_state(vamp_ctx* ctx, double* theta, double* lnprob, int64_t* n_accept,
+                           int64_t* step);
+int vamp_sampler_set_state(vamp_ctx* ctx, const double* theta, const double* lnprob, int64_t step);
+/* HIP-event time (ms) and launch count of the half-step kernel since the last reset; used by
+ * bench.py for the roofline line */
+int vamp_kernel_timing(vamp_ctx* ctx, int enable, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAMP_HIP_H */

@@ -1,0 +1,266 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and
+the committed golden vectors.
+
+Stated tolerances (fp64 / accurate-wofz path):
+  Re w(z)       relative error <= 1e-13 against scipy.special.wofz wherever w > 1e-300
+                (scipy's own claim is 1e-13), <= 2e-14 against the mpmath column
+  tau_k, flux   relative <= 1e-12
+  chi^2         relative <= 1e-11
+  lnprob        |delta| <= 1e-9 * max(1, |lnprob|), identical finite/-inf pattern   
+  sampler       identical accept/reject decisions, positions to 1e-10 relative over 10-12 steps
+fp32 / Humlicek-W4 path (BASELINE.json config 5): Re w relative <= 2e-4 for y > 1e-6;
+  chi^2 relative <= 1e-3 on fixtures whose chi^2 is not dominated by saturated cores.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import vamp_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(g, name):
+    K = int(name.split("_K")[1].split("_")[0])
+    mode = int(name.split("_m")[1].split("_")[0])
+    sd = bool(int(name.split("_sd")[1]))
+    nbz = g[name + "_nbz"] if mode == vo.MODE_NBZ3 else None
+    return g[name + "_x"], g[name + "_flux"], g[name + "_noise"], K, mode, sd, nbz
+
+
+def test_device_wofz_matches_scipy_and_mpmath(hip_ctx):
+    g = load_golden("wofz_grid.npz")
+    x, y, w = g["x"], g["y"], g["re_w"]
+    out = hip_ctx.wofz_re(x, y)
+    ok = w > 1e-300
+    assert not np.isnan(out).any()
+    rel = np.abs(out[ok] - w[ok]) / w[ok]
+    assert rel.max() < 1e-13, (rel.max(), x[ok][rel.argmax()], y[ok][rel.argmax()])
+    relm = np.abs(out[g["mp_idx"]] - g["mp_re_w"]) / g["mp_re_w"]
+    assert relm.max() < 2e-14
+    # symmetric in x
+    assert np.array_equal(hip_ctx.wofz_re(-x[:500], y[:500]), out[:500])
+
+
+def test_lnprob_matches_golden(hip_ctx):
+    g = load_golden("lnprob_cases.npz")
+    for name in g["cases"]:
+        name = str(name)
+        x, f, n, K, mode, sd, nbz = _case(g, name)
+        hip_ctx.set_regions(x, f, n, K, mode=mode, sample_sd=sd, nbz=None if nbz is None else nbz[None, :])
+        th = g[name + "_theta"]
+        got, chi = hip_ctx.lnprob(th, return_chi2=True)
+        want, wchi = g[name + "_lnprob"], g[name + "_chi2"]
+        fin = np.isfinite(want)
+        assert np.array_equal(fin, np.isfinite(got)), name
+        assert np.all(got[~fin] == -np.inf), name
+        err = np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))
+        assert err.max() <= 1e-9, (name, err.max())
+        assert np.max(np.abs(chi[fin] - wchi[fin]) / wchi[fin]) <= 1e-11, name
+        tau, flux = hip_ctx.model(th[0])
+        t0 = g[name + "_tau0"]
+        big = t0 > 1e-290
+        assert np.max(np.abs(tau[big] - t0[big]) / t0[big]) <= 1e-12, name
+        assert np.allclose(flux, g[name + "_flux0"], rtol=1e-12, atol=1e-300), name
+
+
+def test_lnprob_include_norm_and_bounds(hip_ctx):
+    g = load_golden("lnprob_cases.npz")
+    name = "H1215_r1_K4_m1_sd0"
+    x, f, n, K, mode, sd, _ = _case(g, name)
+    th = g[name + "_theta"]
+    bounds = np.array([[x[2], x[-3], 5.0, 9.0]])
+    hip_ctx.set_regions(x, f, n, K, mode=mode, include_norm=True, bounds=bounds)
+    r = vo.Region(x=x, flux=f, noise=n, n_comp=K, mode=mode, include_norm=True, c_lo=x[2], c_hi=x[-3], sigma_max=5.0, fwhm_max=9.0)
+    want = vo.log_prob_batch(r, th)
+    got = hip_ctx.lnprob(th)
+    fin = np.isfinite(want)
+    assert np.array_equal(fin, np.isfinite(got))
+    assert fin.sum() >= 1
+    assert np.max(np.abs(got[fin] - want[fin]) / np.maximum(1, np.abs(want[fin]))) <= 1e-9
+
+
+def test_multi_region_batch_matches_single(hip_ctx):
+    """Ragged CSR batch of regions == the same regions uploaded one at a time."""
+    g = load_golden("lnprob_cases.npz")
+    names = [f"H1215_r{i}_K4_m1_sd0" for i in range(3)] + [f"CII1036_r{i}_K4_m1_sd0" for i in range(4)]
+    xs, fs, ns = [g[n + "_x"] for n in names], [g[n + "_flux"] for n in names], [g[n + "_noise"] for n in names]
+    hip_ctx.set_regions(xs, fs, ns, 4, mode=vo.MODE_VOIGT4)
+    for r, name in enumerate(names):
+        got = hip_ctx.lnprob(g[name + "_theta"], region=r)
+        want = g[name + "_lnprob"]
+        fin = np.isfinite(want)
+        assert np.array_equal(fin, np.isfinite(got))
+        assert np.max(np.abs(got[fin] - want[fin]) / np.maximum(1, np.abs(want[fin]))) <= 1e-9
+
+
+def test_stretch_injected_draws_parity(hip_ctx):
+    g = load_golden("stretch_traj.npz")
+    hip_ctx.set_regions(g["x"], g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)
+    hip_ctx.sampler_init(g["X0"], seed=1, split_block=16)
+    X, lnp, _, _ = hip_ctx.get_state()
+    assert np.allclose(lnp, g["lnp0"], rtol=1e-10)
+    for i in range(g["active"].shape[0]):
+        hip_ctx.half_step_ext(g["active"][i], g["partner"][i], g["zz"][i], g["logu"][i])
+        X, lnp, nacc, _ = hip_ctx.get_state()
+        # identical accept/reject decisions <=> identical set of changed rows
+        assert np.allclose(X, g["X_after"][i], rtol=1e-10, atol=1e-12), i
+        assert np.allclose(lnp, g["lnp_after"][i], rtol=1e-9, atol=1e-9), i
+
+
+@pytest.mark.parametrize("block", [8, 16])
+def test_stretch_philox_trajectory_parity(hip_ctx, block):
+    g = load_golden("stretch_traj.npz")
+    hip_ctx.set_regions(g["x"], g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)
+    hip_ctx.sampler_init(g["X0"], seed=0x1234ABCD5678EF01, a=2.0, split_block=block)
+    res = hip_ctx.run(12)
+    assert np.allclose(res["chain"], g[f"philox_chain_b{block}"], rtol=1e-10, atol=1e-12)
+    assert np.allclose(res["lnprob"], g[f"philox_lnp_b{block}"], rtol=1e-9, atol=1e-9)
+    assert np.array_equal(res["n_accept"], g[f"philox_nacc_b{block}"])
+
+
+def test_sampler_resume_and_thin(hip_ctx):
+    """run(12) == run(5) + run(7); thinning keeps every 3rd sample; get/set_state round trip."""
+    g = load_golden("stretch_traj.npz")
+    hip_ctx.set_regions(g["x"], g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)
+    hip_ctx.sampler_init(g["X0"], seed=77, split_block=16)
+    full = hip_ctx.run(12)
+    hip_ctx.sampler_init(g["X0"], seed=77, split_block=16)
+    a = hip_ctx.run(5)
+    X, lnp, nacc, step = hip_ctx.get_state()
+    assert step == 5
+    hip_ctx.set_state(X, lnp, step)
+    b = hip_ctx.run(7)
+    assert np.array_equal(np.concatenate([a["chain"], b["chain"]]), full["chain"])
+    hip_ctx.sampler_init(g["X0"], seed=77, split_block=16)
+    t = hip_ctx.run(12, thin=3)
+    assert np.array_equal(t["chain"], full["chain"][2::3])
+
+
+def test_sampler_multi_region_matches_oracle(hip_ctx):
+    """Two regions sampled in one launch per half-step follow the oracle's per-region chains."""
+    g = load_golden("lnprob_cases.npz")
+    names = ["H1215_r0_K1_m1_sd0", "H1215_r2_K1_m1_sd0"]
+    rng = np.random.default_rng(5)
+    xs, fs, ns, X0s, regs = [], [], [], [], []
+    for name in names:
+        x, f, n = g[name + "_x"], g[name + "_flux"], g[name + "_noise"]
+        r = vo.Region(x=x, flux=f, noise=n, n_comp=1, mode=vo.MODE_VOIGT4)
+        X0 = np.stack([rng.uniform(0.3, 1.5, 16), rng.uniform(-4, 4, 16), rng.uniform(0.5, 3, 16), rng.uniform(2, 8, 16)], 1)
+        xs.append(x); fs.append(f); ns.append(n); X0s.append(X0); regs.append(r)
+    hip_ctx.set_regions(xs, fs, ns, 1, mode=vo.MODE_VOIGT4)
+    hip_ctx.sampler_init(X0s, seed=2024, split_block=8)
+    res = hip_ctx.run(6)
+    for ri, r in enumerate(regs):
+        fn = lambda q, r=r: vo.log_prob_batch(r, q)
+        chain, lchain, nacc = vo.run_sampler(fn, X0s[ri], fn(X0s[ri]), 6, seed=2024, block=8, region=ri, walker_off=ri * 16)
+        assert np.allclose(res["chain"][ri], chain, rtol=1e-10, atol=1e-12)
+        assert np.array_equal(res["n_accept"][ri], nacc)
+
+
+def test_sampler_sd_mode_and_acceptance(hip_ctx):
+    """Reference-form likelihood (free sd, vpfits.py:39): stored lnprob equals a fresh evaluation
+    of the final positions, and the acceptance fraction is sane."""
+    g = load_golden("lnprob_cases.npz")
+    name = "H1215_r0_K2_m1_sd1"
+    x, f, n, K, mode, sd, _ = _case(g, name)
+    hip_ctx.set_regions(x, f, n, K, mode=mode, sample_sd=True)
+    rng = np.random.default_rng(11)
+    W = 256
+    X0 = np.empty((W, 9))
+    for k in range(2):
+        X0[:, 4 * k:4 * k + 4] = np.stack([rng.uniform(0.5, 2, W), rng.uniform(-6, 6, W), rng.uniform(0.5, 2, W), rng.uniform(3, 9, W)], 1)
+    X0[:, 8] = rng.uniform(0.05, 0.5, W)
+    hip_ctx.sampler_init(X0, seed=5, split_block=64)
+    res = hip_ctx.run(200, store_chain=False)
+    X, lnp, nacc, step = hip_ctx.get_state()
+    assert step == 200
+    fresh = hip_ctx.lnprob(X)
+    assert np.allclose(fresh, lnp, rtol=1e-12, atol=1e-9)
+    r = vo.Region(x=x, flux=f, noise=n, n_comp=2, mode=mode, sample_sd=True)
+    assert np.allclose(vo.log_prob_batch(r, X[:32]), lnp[:32], rtol=1e-9, atol=1e-9)
+    acc = nacc.mean() / 200
+    assert 0.05 < acc < 0.8, acc
+    assert lnp.mean() > hip_ctx.lnprob(X0).mean()          # the ensemble climbed
+
+
+def test_error_behaviour(hip_ctx):
+    import vamp_amd
+    g = load_golden("stretch_traj.npz")
+    hip_ctx.set_regions(g["x"], g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)
+    with pytest.raises(ValueError):
+        hip_ctx.lnprob(np.zeros((4, 3)))
+    with pytest.raises(vamp_amd._lib.VampError) as e:
+        hip_ctx.sampler_init(g["X0"][:15], seed=1, split_block=5)
+    assert e.value.code == -1
+    hip_ctx.sampler_init(g["X0"], seed=1, split_block=16)
+    with pytest.raises(vamp_amd._lib.VampError):          # partner inside the active set
+        hip_ctx.half_step_ext([0, 1], [1, 2], [1.0, 1.0], [0.0, 0.0])
+    with pytest.raises(vamp_amd._lib.VampError):          # index out of range
+        hip_ctx.half_step_ext([0], [99], [1.0], [0.0])
+    with pytest.raises(vamp_amd._lib.VampError):
+        vamp_amd.HipContext(device=0, dtype=vamp_amd.F32, wofz_kind=0)
+    # non-finite parameters are -inf, not errors
+    th = g["X0"].copy()
+    th[0, 0] = np.nan
+    th[1, 3] = np.inf
+    out = hip_ctx.lnprob(th)
+    assert out[0] == -np.inf and out[1] == -np.inf and np.isfinite(out[2:]).all()
+
+
+def test_fp32_humlicek_path():
+    """BASELINE.json config 5: fp32 pixel arithmetic + Humlicek W4 against the fp64 oracle."""
+    import vamp_amd
+    from scipy.special import wofz
+    g = load_golden("wofz_grid.npz")
+    ctx = vamp_amd.HipContext(device=0, dtype=vamp_amd.F32)
+    try:
+        x, y = g["x"].astype(np.float32).astype(np.float64), g["y"].astype(np.float32).astype(np.float64)
+        w = wofz(x + 1j * y).real
+        out = ctx.wofz_re(x, y)
+        m = (y > 1e-6) & (w > 1e-30) & (x < 1e15)
+        assert np.max(np.abs(out[m] - w[m]) / w[m]) < 2e-4
+        c = load_golden("lnprob_cases.npz")
+        for name in ("H1215_r0_K4_m1_sd0", "CII1036_r1_K4_m1_sd0", "H1215_r1_K2_m0_sd0"):
+            xx, f, n, K, mode, sd, _ = _case(c, name)
+            ctx.set_regions(xx, f, n, K, mode=mode)
+            th = c[name + "_theta"]
+            got, chi = ctx.lnprob(th, return_chi2=True)
+            want, wchi = c[name + "_lnprob"], c[name + "_chi2"]
+            fin = np.isfinite(want) & (th[:, 3 if mode == 1 else 2] > 1e-3)   # fp32 cannot resolve G ~ 1e-6 px
+            assert np.array_equal(np.isfinite(want), np.isfinite(got)), name
+            rel = np.abs(chi[fin] - wchi[fin]) / wchi[fin]
+            assert np.median(rel) < 1e-4 and rel.max() < 1e-3, (name, rel.max())
+    finally:
+        ctx.close()
+
+
+def test_full_size_properties(hip_ctx):
+    """Headline shape (P = 16384, K = 16; fewer walkers): properties that need no CPU reference.
+    (1) batch-position independence, (2) component-permutation invariance, (3) tau is the sum of
+    single-component taus, (4) a down-scaled twin agrees with the oracle."""
+    from bench import make_workload
+    wl = make_workload(P=16384, K=16, W=64, seed=20240517, nbz=False)
+    hip_ctx.set_regions(wl["x"], wl["flux"], wl["noise"], 16, mode=vo.MODE_VOIGT4)
+    th = wl["theta0"]
+    a = hip_ctx.lnprob(th)
+    b = hip_ctx.lnprob(th[::-1].copy())[::-1]
+    assert np.array_equal(a, b)
+    perm = np.random.default_rng(0).permutation(16)
+    thp = th.reshape(64, 16, 4)[:, perm, :].reshape(64, 64)
+    c = hip_ctx.lnprob(thp)
+    assert np.allclose(a, c, rtol=1e-11)
+    tau, flux = hip_ctx.model(th[0])
+    assert np.allclose(flux, np.exp(-tau.sum(0)), rtol=1e-13)
+    # single-component contexts reproduce each row of tau
+    hip_ctx.set_regions(wl["x"], wl["flux"], wl["noise"], 1, mode=vo.MODE_VOIGT4,
+                        bounds=np.array([[wl["x"][0], wl["x"][-1], 1e9, 1e9]]))
+    for k in (0, 7, 15):
+        t1, _ = hip_ctx.model(th[0, 4 * k:4 * k + 4])
+        assert np.array_equal(t1[0], tau[k])
+    small = make_workload(P=256, K=16, W=64, seed=3, nbz=False)
+    hip_ctx.set_regions(small["x"], small["flux"], small["noise"], 16, mode=vo.MODE_VOIGT4)
+    r = vo.Region(x=small["x"], flux=small["flux"], noise=small["noise"], n_comp=16, mode=vo.MODE_VOIGT4)
+    want = vo.log_prob_batch_fast(r, small["theta0"])
+    got = hip_ctx.lnprob(small["theta0"])
+    assert np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) <= 1e-9

@@ -1,0 +1,76 @@
+"""ctypes binding of libvamp_hip.so (include/vamp_hip.h).
+
+There is no fallback: if the shared library has not been built (``__graft_entry__.build()`` or
+``python -m vamp_amd.build``) importing a symbol raises, and every compute entry point needs a
+GPU.  The signatures below are the single place where the C ABI is spelled out in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvamp_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_void_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/vamp_hip.h one to one
+SIGNATURES = {
+    "vamp_version": (C.c_int, []),
+    "vamp_last_error": (C.c_char_p, []),
+    "vamp_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "vamp_ctx_create": (C.c_int, [c_void_pp, C.c_int, C.c_int, C.c_int]),
+    "vamp_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "vamp_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vamp_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "vamp_set_regions": (C.c_int, [C.c_void_p, C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_int32_p,
+                                   C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),
+    "vamp_region_ndim": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "vamp_lnprob": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    "vamp_model": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "vamp_wofz_re": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    "vamp_sampler_init": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_uint64, C.c_double, C.c_int32]),
+    "vamp_sampler_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int64_p, c_int64_p]),
+    "vamp_sampler_bind_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vamp_sampler_state_ptrs": (C.c_int, [C.c_void_p, c_void_pp, c_void_pp, c_int64_p, c_int64_p]),
+    "vamp_sampler_half_step": (C.c_int, [C.c_void_p, C.c_int]),
+    "vamp_sampler_half_step_ext": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_int32_p, c_int32_p, c_double_p, c_double_p]),
+    "vamp_sampler_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_double_p, c_double_p, c_int64_p, c_double_p]),
+    "vamp_sampler_get_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int64_p, c_int64_p]),
+    "vamp_sampler_set_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int64]),
+    "vamp_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_int64_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvamp_hip.so and attach the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `python -c 'import "
+            "__graft_entry__ as g; g.build()'`).  vamp_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class VampError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvamp_hip error {code}: {msg}")
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise VampError(rc, load().vamp_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,1038 @@
+// vamp_hip.hip -- MI355X (gfx950) kernels + C ABI for VAMP's MCMC hot path.
+//
+// Replaces, below the Python surface of class VPfit (reference vamp_1.0/vpfits.py:33):
+//   * the per-proposal evaluation of the PyMC model graph -- profile closures
+//     (vpfits.py:254-260, 299-305), `total` = Tau2flux(sum(profiles)) (vpfits.py:334-336,
+//     physics.py:105), the observed Normal likelihood (vpfits.py:39,341) and the priors
+//     (vpfits.py:239-252, 283-297);
+//   * the sampler loop of mcmc_fit / find_bic (vpfits.py:361-395, 420-425), by the stretch move
+//     of Goodman & Weare (2010) with emcee's red/blue semantics.
+//
+// Execution shape: ONE 64-lane wavefront per walker (4 walkers per 256-thread workgroup).
+//   stage   lanes 0..K-1 turn the walker's parameters into per-line records in LDS
+//           (centroid, x-scale, damping y, tau scale, pole factor) and all lanes fill the per-line
+//           table 1/(u_n^2 + y^2) used by the near-axis Voigt rule; priors are summed here.
+//   sweep   lane l takes pixels l, l+64, ...: coalesced 512-byte reads of x / flux / 1/sigma
+//           (shared by every walker -> L2/MALL resident), tau = sum_k tau_k in registers,
+//           flux = exp(-tau), chi^2 partial per lane.
+//   reduce  xor-shuffle tree over the wavefront; lane 0 owns the result.
+//   move    (sampler kernel) proposal q = c - (c - s) z is formed in LDS before `stage`, and the
+//           accept test / state update follow `reduce` in the same launch.
+// No MFMA (nothing here is a contraction), no atomics, no inter-workgroup communication.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/vamp_hip.h"
+#include "voigt_math.hpp"
+
+namespace {
+
+constexpr int KMAX = VAMP_MAX_COMPONENTS;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
+constexpr int DMAX = 4 * KMAX + 1;
+
+constexpr double C_LIGHT = 2.98e8;     // physics.py:3 (the reference's value)
+constexpr double SIGMA0 = 0.0263;      // physics.py:4
+constexpr double SQRT_LN2 = 0.83255461115769775635;
+constexpr double SQRT_PI = 1.77245385090551602730;
+constexpr double FWHM_PER_SIGMA = 2.35482004503094938202;   // 2 sqrt(2 ln 2), vpfits.py:88,326
+constexpr double NEG_INF = -__builtin_huge_val();
+
+// ---------------------------------------------------------------------------------------
+// device-side description of one region (one posterior)
+// ---------------------------------------------------------------------------------------
+struct RegionDev {
+    long long pix_off;     // into x / flux / wt
+    long long theta_off;   // doubles: start of this region's [W, D] block in the sampler state
+    long long walker_off;  // first global walker id of this region in the sampler state
+    int P, K, mode, D;     // D = q*K (+1 if sample_sd)
+    int sample_sd, q, pad0, pad1;
+    double c_lo, c_hi;     // centroid prior (vpfits.py:250,293)
+    double w_max;          // sigma_max (GAUSS3, vpfits.py:320) or fwhm_max (vpfits.py:326)
+    double lp_c, lp_w;     // -log(c_hi - c_lo), -log(w_max): uniform log-densities
+    double l_fixed, line, x_origin, x_scale;   // NBZ3
+    double norm_const;     // -1/2 sum log(2 pi sigma^2) or 0
+};
+
+struct LineRec {           // per (walker, component), lives in LDS
+    double c;              // centroid
+    double s;              // Voigt: 2 sqrt(ln2)/G ; Gauss: 1/sigma
+    double y;              // Voigt: L sqrt(ln2)/G
+    double amp;            // Voigt: A L sqrt(pi) sqrt(ln2) / G ; Gauss: A
+    double pole;           // core_pole_factor(y)
+};
+
+struct WaveLds {
+    double theta[DMAX + 3];
+    LineRec line[KMAX];
+    double dtab[KMAX][vamp::DTAB_N];
+    float linef[KMAX][4];  // fp32 path: c, s, y, amp
+};
+
+// ---------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// literal restatement of vpfits.py:239-244: -inf for v<0, else log(v*exp(-v))
+__device__ __forceinline__ double xexp_logp(double v) {
+    if (!(v >= 0.0) || !isfinite(v)) return NEG_INF;
+    return log(v * exp(-v));
+}
+__device__ __forceinline__ double uniform_logp(double v, double lo, double hi, double lp) {
+    return (v >= lo && v <= hi) ? lp : NEG_INF;
+}
+
+// Turn theta (in LDS) into line records + prior.  Returns log-prior on every lane.
+__device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, int lane, bool want_f32) {
+    double lp = 0.0;
+    const int K = R.K;
+    if (lane < K) {
+        const double* t = &L.theta[R.q * lane];
+        double a, c, Lw = 0.0, G = 0.0, sg = 0.0;
+        if (R.mode == VAMP_GAUSS3) {
+            a = t[0]; c = t[1]; sg = t[2];
+            lp = xexp_logp(a) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) + uniform_logp(sg, 0.0, R.w_max, R.lp_w);
+        } else if (R.mode == VAMP_VOIGT4) {
+            a = t[0]; c = t[1]; Lw = t[2]; G = t[3];
+            lp = xexp_logp(a) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) +
+                 uniform_logp(Lw, 0.0, R.w_max, R.lp_w) + uniform_logp(G, 0.0, R.w_max, R.lp_w);
+        } else {   // NBZ3: inverse of physics.py:15,27,120,134
+            const double sig = t[1] * 1.0e3 * 1.41421356237309514547 / (2.355 * (R.line * 1.0e-10));
+            a = t[0] * SIGMA0 / (sig * 2.50662827463100024161);
+            c = (C_LIGHT / (R.line * (1.0 + t[2]) * 1.0e-10) - R.x_origin) / R.x_scale;
+            G = (sig / R.x_scale) * FWHM_PER_SIGMA;
+            Lw = R.l_fixed;
+            lp = xexp_logp(a) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) + uniform_logp(G, 0.0, R.w_max, R.lp_w);
+        }
+        LineRec rec;
+        rec.c = c;
+        if (R.mode == VAMP_GAUSS3) {
+            rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0;
+        } else {
+            rec.s = 2.0 * SQRT_LN2 / G;
+            rec.y = Lw * SQRT_LN2 / G;
+            rec.amp = a * Lw * SQRT_PI * SQRT_LN2 / G;     // evaluation order of the oracle
+            rec.pole = vamp::core_pole_factor(rec.y);
+        }
+        L.line[lane] = rec;
+        if (want_f32) {
+            L.linef[lane][0] = (float)rec.c; L.linef[lane][1] = (float)rec.s;
+            L.linef[lane][2] = (float)rec.y; L.linef[lane][3] = (float)rec.amp;
+        }
+    }
+    if (R.sample_sd && lane == KMAX) {      // one otherwise idle lane: sd ~ U(0,1), vpfits.py:39
+        lp = uniform_logp(L.theta[R.D - 1], 0.0, 1.0, 0.0);
+    }
+    lp = wave_sum(lp);
+    __builtin_amdgcn_wave_barrier();
+    if (R.mode != VAMP_GAUSS3 && !want_f32) {
+        for (int e = lane; e < K * vamp::DTAB_N; e += 64) {
+            const int k = e / vamp::DTAB_N, n = e % vamp::DTAB_N;
+            L.dtab[k][n] = vamp::core_dtab_entry(n, L.line[k].y);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return lp;
+}
+
+// chi^2 sweep, fp64 pixel arithmetic.  Returns sum over the wave's pixels of ((f-m) w)^2.
+__device__ __forceinline__ double sweep_f64(const RegionDev& R, const WaveLds& L, const double* __restrict__ x,
+                                            const double* __restrict__ f, const double* __restrict__ wt, int lane) {
+    double chi = 0.0;
+    const int K = R.K, P = R.P;
+    const bool gauss = (R.mode == VAMP_GAUSS3);
+    for (int i = lane; i < P; i += 64) {
+        const double xi = x[i];
+        double tau = 0.0;
+        if (gauss) {
+            for (int k = 0; k < K; ++k) {
+                const double u = (xi - L.line[k].c) * L.line[k].s;
+                tau += L.line[k].amp * exp(-0.5 * (u * u));
+            }
+        } else {
+            for (int k = 0; k < K; ++k) {
+                const double X = fabs(xi - L.line[k].c) * L.line[k].s;
+                const double H = vamp::voigt_H(X, L.line[k].y, L.dtab[k], L.line[k].pole);
+                tau += L.line[k].amp * H;
+            }
+        }
+        const double m = exp(-tau);
+        const double r = (f[i] - m) * wt[i];
+        chi = fma(r, r, chi);
+    }
+    return wave_sum(chi);
+}
+
+// fp32 pixel arithmetic (Humlicek W4), chi^2 accumulated in fp64 (SURVEY section 7 hard parts).
+__device__ __forceinline__ double sweep_f32(const RegionDev& R, const WaveLds& L, const float* __restrict__ x,
+                                            const float* __restrict__ f, const float* __restrict__ wt, int lane) {
+    double chi = 0.0;
+    const int K = R.K, P = R.P;
+    const bool gauss = (R.mode == VAMP_GAUSS3);
+    for (int i = lane; i < P; i += 64) {
+        const float xi = x[i];
+        float tau = 0.0f;
+        if (gauss) {
+            for (int k = 0; k < K; ++k) {
+                const float u = (xi - L.linef[k][0]) * L.linef[k][1];
+                tau += L.linef[k][3] * __expf(-0.5f * (u * u));
+            }
+        } else {
+            for (int k = 0; k < K; ++k) {
+                const float X = fabsf(xi - L.linef[k][0]) * L.linef[k][1];
+                tau += L.linef[k][3] * vamp::humlicek_w4_re(X, L.linef[k][2]);
+            }
+        }
+        const float m = __expf(-tau);
+        const float r = (f[i] - m) * wt[i];
+        chi += (double)r * (double)r;
+    }
+    return wave_sum(chi);
+}
+
+// log-likelihood from the reduced sum (both forms of SURVEY Appendix A)
+__device__ __forceinline__ double loglike_from_sum(const RegionDev& R, const WaveLds& L, double ssum) {
+    if (R.sample_sd) {
+        const double sd = L.theta[R.D - 1];
+        const double t = 1.0 / (sd * sd);
+        return (double)R.P * 0.5 * log(t / (2.0 * vamp::PI)) - 0.5 * t * ssum;   // vpfits.py:39,341
+    }
+    return -0.5 * ssum + R.norm_const;                                            // vpfits.py:118
+}
+
+struct PixPtrs {
+    const double* x; const double* f; const double* wt;       // fp64 copies
+    const float* xf; const float* ff; const float* wtf;       // fp32 copies (may be null)
+};
+
+template <bool F32>
+__device__ __forceinline__ double wave_lnprob(const RegionDev& R, WaveLds& L, const PixPtrs& px, int lane, double* chi_out) {
+    const double lp = stage_lines(R, L, lane, F32);
+    if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
+        if (chi_out) *chi_out = __builtin_nan("");
+        return NEG_INF;
+    }
+    double ssum;
+    if (F32) ssum = sweep_f32(R, L, px.xf + R.pix_off, px.ff + R.pix_off, px.wtf + R.pix_off, lane);
+    else ssum = sweep_f64(R, L, px.x + R.pix_off, px.f + R.pix_off, px.wt + R.pix_off, lane);
+    if (chi_out) *chi_out = ssum;
+    double v = lp + loglike_from_sum(R, L, ssum);
+    if (v != v) v = NEG_INF;                 // NaN -> -inf (emcee convention)
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(BLOCK) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
+                                                  long long W, const double* __restrict__ theta,
+                                                  double* __restrict__ lnprob, double* __restrict__ chi2) {
+    __shared__ WaveLds lds[WAVES_PER_BLOCK];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (w >= W) return;
+    const RegionDev R = regions[region];
+    WaveLds& L = lds[wave];
+    for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[w * R.D + d];
+    __builtin_amdgcn_wave_barrier();
+    double chi;
+    const double v = wave_lnprob<F32>(R, L, px, lane, &chi);
+    if (lane == 0) {
+        lnprob[w] = v;
+        if (chi2) chi2[w] = chi;
+    }
+}
+
+// tau_k[P] and flux[P] for one parameter vector (one thread per pixel)
+__global__ __launch_bounds__(BLOCK) void k_model(const RegionDev* __restrict__ regions, int region, PixPtrs px,
+                                                 const double* __restrict__ theta, double* __restrict__ tau_comp,
+                                                 double* __restrict__ flux_model) {
+    __shared__ WaveLds lds[WAVES_PER_BLOCK];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const RegionDev R = regions[region];
+    WaveLds& L = lds[wave];
+    for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[d];
+    __builtin_amdgcn_wave_barrier();
+    (void)stage_lines(R, L, lane, false);
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= R.P) return;
+    const double xi = px.x[R.pix_off + i];
+    double tau = 0.0;
+    for (int k = 0; k < R.K; ++k) {
+        double tk;
+        if (R.mode == VAMP_GAUSS3) {
+            const double u = (xi - L.line[k].c) * L.line[k].s;
+            tk = L.line[k].amp * exp(-0.5 * (u * u));
+        } else {
+            const double X = fabs(xi - L.line[k].c) * L.line[k].s;
+            tk = L.line[k].amp * vamp::voigt_H(X, L.line[k].y, L.dtab[k], L.line[k].pole);
+        }
+        if (tau_comp) tau_comp[(long long)k * R.P + i] = tk;
+        tau += tk;
+    }
+    if (flux_model) flux_model[i] = exp(-tau);
+}
+
+template <bool F32>
+__global__ __launch_bounds__(BLOCK) void k_wofz(long long n, const double* __restrict__ x, const double* __restrict__ y,
+                                                double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (F32) {
+        out[i] = (double)vamp::humlicek_w4_re(fabsf((float)x[i]), (float)y[i]);
+    } else {
+        double dtab[vamp::DTAB_N];
+        for (int k = 0; k < vamp::DTAB_N; ++k) dtab[k] = vamp::core_dtab_entry(k, y[i]);
+        out[i] = vamp::voigt_H(fabs(x[i]), y[i], dtab, vamp::core_pole_factor(y[i]));
+    }
+}
+
+// ---- counter-based RNG: Philox4x32-10 (Salmon et al., SC'11) ------------------------------
+struct U4 { unsigned c0, c1, c2, c3; };
+__device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c.c0;
+        const unsigned long long p1 = 0xCD9E8D57ull * c.c2;
+        U4 n;
+        n.c0 = (unsigned)(p1 >> 32) ^ c.c1 ^ k0;
+        n.c1 = (unsigned)p1;
+        n.c2 = (unsigned)(p0 >> 32) ^ c.c3 ^ k1;
+        n.c3 = (unsigned)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ double u53(unsigned hi, unsigned lo) {
+    return (double)((((unsigned long long)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+constexpr unsigned STREAM_MOVE = 0, STREAM_ACCEPT = 1, STREAM_SPLIT = 2;
+
+// keyed bijection of [0, block): affine-multiply / xorshift rounds on the next power of two,
+// cycle-walking back into range (DESIGN.md "red/blue split")
+__device__ __forceinline__ unsigned split_perm(unsigned long long seed, unsigned step, unsigned chunk, unsigned region,
+                                               unsigned slot, unsigned block) {
+    const U4 r = philox4x32_10({chunk, step, STREAM_SPLIT, region}, (unsigned)seed, (unsigned)(seed >> 32));
+    int bits = 32 - __builtin_clz((block - 1) | 1u);
+    if (bits < 1) bits = 1;
+    const unsigned long long mask = (1ull << bits) - 1ull;
+    int sh = bits / 2;
+    if (sh < 1) sh = 1;
+    const unsigned long long m0 = ((unsigned long long)r.c0 << 1) | 1ull, m2 = ((unsigned long long)r.c2 << 1) | 1ull;
+    unsigned long long v = slot;
+    for (;;) {
+        v = (v * m0 + r.c1) & mask;  v ^= v >> sh;
+        v = (v * m2 + r.c3) & mask;  v ^= v >> sh;
+        v = (v * 0x9E3779B1ull + (r.c0 ^ r.c3)) & mask;  v ^= v >> sh;
+        if (v < block) return (unsigned)v;
+    }
+}
+
+struct SamplerDev {
+    const RegionDev* regions;
+    int n_regions;
+    long long W;                 // walkers per region
+    int split_block;
+    double a;
+    unsigned long long seed;
+    double* X;                   // concatenated [W, D_r] blocks
+    double* lnp;                 // [n_regions * W]
+    long long* n_accept;         // [n_regions * W]
+    long long slot_begin, slot_end;   // this ctx's share of the n_regions*W/2 active slots
+};
+
+// One half-step of the stretch move, one wavefront per active walker.
+//   EXT = draws supplied by the host (deterministic-parity hook); else Philox in-kernel.
+template <bool F32, bool EXT>
+__global__ __launch_bounds__(BLOCK) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
+                                                     long long ext_n, const int* __restrict__ ext_active,
+                                                     const int* __restrict__ ext_partner, const double* __restrict__ ext_z,
+                                                     const double* __restrict__ ext_logu) {
+    __shared__ WaveLds lds[WAVES_PER_BLOCK];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long halfW = S.W >> 1;
+    long long slot = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
+    int region;
+    long long ws, wc;            // local walker ids (within the region) of mover and partner
+    double z, logu;
+    if (EXT) {
+        if (slot >= ext_n) return;
+        region = ext_region;
+        ws = ext_active[slot]; wc = ext_partner[slot]; z = ext_z[slot]; logu = ext_logu[slot];
+    } else {
+        slot += S.slot_begin;
+        if (slot >= S.slot_end) return;
+        region = (int)(slot / halfW);
+        const long long a_loc = slot - (long long)region * halfW;          // active slot inside the region
+        const unsigned hb = (unsigned)(S.split_block >> 1);
+        const unsigned chunk = (unsigned)(a_loc / hb);
+        const unsigned pos = (unsigned)(a_loc % hb);
+        ws = (long long)chunk * S.split_block +
+             split_perm(S.seed, step, chunk, (unsigned)region, pos + (half ? hb : 0u), (unsigned)S.split_block);
+        const long long gid = S.regions[region].walker_off + ws;
+        const unsigned k0 = (unsigned)S.seed, k1 = (unsigned)(S.seed >> 32);
+        const U4 r = philox4x32_10({(unsigned)gid, step, ((unsigned)half << 8) | STREAM_MOVE, (unsigned)(gid >> 32)}, k0, k1);
+        const double u1 = u53(r.c0, r.c1);
+        const double t = (S.a - 1.0) * u1 + 1.0;
+        z = t * t / S.a;
+        const unsigned long long j = __umul64hi(((unsigned long long)r.c2 << 32) | r.c3, (unsigned long long)halfW);
+        const unsigned cchunk = (unsigned)(j / hb);
+        const unsigned cpos = (unsigned)(j % hb);
+        wc = (long long)cchunk * S.split_block +
+             split_perm(S.seed, step, cchunk, (unsigned)region, cpos + (half ? 0u : hb), (unsigned)S.split_block);
+        const U4 r2 = philox4x32_10({(unsigned)gid, step, ((unsigned)half << 8) | STREAM_ACCEPT, (unsigned)(gid >> 32)}, k0, k1);
+        const double u2 = u53(r2.c0, r2.c1);
+        logu = u2 > 0.0 ? log(u2) : NEG_INF;
+    }
+    const RegionDev R = S.regions[region];
+    WaveLds& L = lds[wave];
+    double* Xs = S.X + R.theta_off + ws * R.D;
+    const double* Xc = S.X + R.theta_off + wc * R.D;
+    for (int d = lane; d < R.D; d += 64) {
+        const double c = Xc[d];
+        L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double lnp_q = wave_lnprob<F32>(R, L, px, lane, nullptr);
+    const long long wg = R.walker_off + ws;
+    const double lnp_s = S.lnp[wg];
+    const double diff = (double)(R.D - 1) * log(z) + lnp_q - lnp_s;
+    const bool accept = logu < diff;                      // false for NaN
+    if (accept) {
+        for (int d = lane; d < R.D; d += 64) Xs[d] = L.theta[d];
+        if (lane == 0) {
+            S.lnp[wg] = lnp_q;
+            S.n_accept[wg] += 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? VAMP_ERR_NOMEM : VAMP_ERR_HIP,            \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+}  // namespace
+
+struct vamp_ctx {
+    int device = 0;
+    int dtype = VAMP_F64;
+    int wofz_kind = VAMP_WOFZ_ACCURATE;
+    bool f32 = false;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // regions
+    int n_regions = 0;
+    std::vector<RegionDev> regions_h;
+    RegionDev* regions_d = nullptr;
+    long long n_pix = 0;
+    double *x_d = nullptr, *f_d = nullptr, *wt_d = nullptr;
+    float *xf_d = nullptr, *ff_d = nullptr, *wtf_d = nullptr;
+    // sampler
+    bool sampler_ready = false;
+    long long W = 0, total_theta = 0, total_walkers = 0;
+    int split_block = 0;
+    double a = 2.0;
+    unsigned long long seed = 0;
+    long long step = 0;
+    double* X_d = nullptr;
+    double* lnp_d = nullptr;
+    bool X_ext = false;
+    long long* nacc_d = nullptr;
+    long long slot_begin = 0, slot_end = 0;
+    int shard_rank = 0, shard_world = 1;
+    // scratch for the ext hook
+    int *ext_act_d = nullptr, *ext_par_d = nullptr;
+    double *ext_z_d = nullptr, *ext_lu_d = nullptr;
+    long long ext_cap = 0;
+    // kernel timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t ev_used = 0;
+    double timing_ms = 0.0;
+    long long timing_launches = 0;
+
+    PixPtrs pix() const { return PixPtrs{x_d, f_d, wt_d, xf_d, ff_d, wtf_d}; }
+};
+
+namespace {
+
+int free_regions(vamp_ctx* c) {
+    for (void* p : {(void*)c->regions_d, (void*)c->x_d, (void*)c->f_d, (void*)c->wt_d, (void*)c->xf_d, (void*)c->ff_d,
+                    (void*)c->wtf_d})
+        if (p) (void)hipFree(p);
+    c->regions_d = nullptr;
+    c->x_d = c->f_d = c->wt_d = nullptr;
+    c->xf_d = c->ff_d = c->wtf_d = nullptr;
+    c->n_regions = 0;
+    c->regions_h.clear();
+    return 0;
+}
+
+int free_sampler(vamp_ctx* c) {
+    if (c->X_d && !c->X_ext) (void)hipFree(c->X_d);
+    if (c->lnp_d && !c->X_ext) (void)hipFree(c->lnp_d);
+    if (c->nacc_d) (void)hipFree(c->nacc_d);
+    c->X_d = nullptr;
+    c->lnp_d = nullptr;
+    c->nacc_d = nullptr;
+    c->sampler_ready = false;
+    return 0;
+}
+
+int flush_timing(vamp_ctx* c) {
+    if (c->ev_used == 0) return 0;
+    HIP_TRY(hipEventSynchronize(c->ev[c->ev_used - 1].second));
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i].first, c->ev[i].second));
+        c->timing_ms += ms;
+        c->timing_launches += 1;
+    }
+    c->ev_used = 0;
+    return 0;
+}
+
+int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n) {
+    SamplerDev S;
+    S.regions = c->regions_d;
+    S.n_regions = c->n_regions;
+    S.W = c->W;
+    S.split_block = c->split_block;
+    S.a = c->a;
+    S.seed = c->seed;
+    S.X = c->X_d;
+    S.lnp = c->lnp_d;
+    S.n_accept = c->nacc_d;
+    S.slot_begin = c->slot_begin;
+    S.slot_end = c->slot_end;
+    const long long n = ext ? ext_n : (c->slot_end - c->slot_begin);
+    if (n <= 0) return 0;
+    const unsigned grid = (unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        if (c->ev_used == c->ev.size()) {
+            if (c->ev.size() >= 4096) {
+                int rc = flush_timing(c);
+                if (rc) return rc;
+            } else {
+                hipEvent_t a, b;
+                HIP_TRY(hipEventCreate(&a));
+                HIP_TRY(hipEventCreate(&b));
+                c->ev.emplace_back(a, b);
+            }
+        }
+        e0 = c->ev[c->ev_used].first;
+        e1 = c->ev[c->ev_used].second;
+        c->ev_used++;
+        HIP_TRY(hipEventRecord(e0, c->stream));
+    }
+    const unsigned step = (unsigned)c->step;
+    const PixPtrs px = c->pix();
+    if (ext) {
+        if (c->f32)
+            hipLaunchKernelGGL((k_half_step<true, true>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step, half, ext_region,
+                               ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d);
+        else
+            hipLaunchKernelGGL((k_half_step<false, true>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step, half, ext_region,
+                               ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d);
+    } else {
+        if (c->f32)
+            hipLaunchKernelGGL((k_half_step<true, false>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step, half, 0, 0ll,
+                               nullptr, nullptr, nullptr, nullptr);
+        else
+            hipLaunchKernelGGL((k_half_step<false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step, half, 0, 0ll,
+                               nullptr, nullptr, nullptr, nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vamp_version(void) { return VAMP_ABI_VERSION; }
+
+const char* vamp_last_error(void) { return g_err.c_str(); }
+
+int vamp_device_count(int* n) {
+    if (!n) return fail(VAMP_ERR_ARG, "vamp_device_count: n is NULL");
+    HIP_TRY(hipGetDeviceCount(n));
+    return VAMP_OK;
+}
+
+int vamp_ctx_create(vamp_ctx** out, int device, int dtype, int wofz_kind) {
+    if (!out) return fail(VAMP_ERR_ARG, "vamp_ctx_create: out is NULL");
+    if (!((dtype == VAMP_F64 && wofz_kind == VAMP_WOFZ_ACCURATE) || (dtype == VAMP_F32 && wofz_kind == VAMP_WOFZ_HUMLICEK_W4)))
+        return fail(VAMP_ERR_ARG, "vamp_ctx_create: supported pairs are (F64, ACCURATE) and (F32, HUMLICEK_W4)");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(VAMP_ERR_ARG, "vamp_ctx_create: no such device");
+    HIP_TRY(hipSetDevice(device));
+    vamp_ctx* c = new (std::nothrow) vamp_ctx();
+    if (!c) return fail(VAMP_ERR_NOMEM, "vamp_ctx_create: host allocation failed");
+    c->device = device;
+    c->dtype = dtype;
+    c->wofz_kind = wofz_kind;
+    c->f32 = (dtype == VAMP_F32);
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(VAMP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return VAMP_OK;
+}
+
+int vamp_ctx_destroy(vamp_ctx* c) {
+    if (!c) return VAMP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_sampler(c);
+    free_regions(c);
+    for (void* p : {(void*)c->ext_act_d, (void*)c->ext_par_d, (void*)c->ext_z_d, (void*)c->ext_lu_d})
+        if (p) (void)hipFree(p);
+    for (auto& p : c->ev) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return VAMP_OK;
+}
+
+int vamp_ctx_set_stream(vamp_ctx* c, void* hip_stream) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_set_stream: ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return VAMP_OK;
+}
+
+int vamp_ctx_synchronize(vamp_ctx* c) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_synchronize: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VAMP_OK;
+}
+
+int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const double* x, const double* flux,
+                     const double* noise, const int32_t* n_comp, int mode, int sample_sd, int include_norm,
+                     const double* bounds, const double* nbz) {
+    if (!c || n_regions <= 0 || !pix_off || !x || !flux || !noise || !n_comp)
+        return fail(VAMP_ERR_ARG, "vamp_set_regions: NULL argument or n_regions <= 0");
+    if (mode != VAMP_GAUSS3 && mode != VAMP_VOIGT4 && mode != VAMP_NBZ3) return fail(VAMP_ERR_ARG, "vamp_set_regions: bad mode");
+    if (mode == VAMP_NBZ3 && !nbz) return fail(VAMP_ERR_ARG, "vamp_set_regions: VAMP_NBZ3 needs nbz");
+    if (pix_off[0] != 0) return fail(VAMP_ERR_ARG, "vamp_set_regions: pix_off[0] must be 0");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_sampler(c);
+    free_regions(c);
+    const int q = (mode == VAMP_VOIGT4) ? 4 : 3;
+    std::vector<RegionDev> R(n_regions);
+    for (int r = 0; r < n_regions; ++r) {
+        const long long P = pix_off[r + 1] - pix_off[r];
+        if (P < 2 || P > 0x7fffffff) return fail(VAMP_ERR_ARG, "vamp_set_regions: a region needs >= 2 pixels");
+        if (n_comp[r] < 1 || n_comp[r] > KMAX) return fail(VAMP_ERR_ARG, "vamp_set_regions: n_comp out of range (1..16)");
+        RegionDev d;
+        std::memset(&d, 0, sizeof(d));
+        d.pix_off = pix_off[r];
+        d.P = (int)P;
+        d.K = n_comp[r];
+        d.mode = mode;
+        d.q = q;
+        d.sample_sd = sample_sd ? 1 : 0;
+        d.D = q * d.K + d.sample_sd;
+        const double* xr = x + pix_off[r];
+        if (bounds) {
+            d.c_lo = bounds[4 * r + 0];
+            d.c_hi = bounds[4 * r + 1];
+            d.w_max = (mode == VAMP_GAUSS3) ? bounds[4 * r + 2] : bounds[4 * r + 3];
+        } else {
+            d.c_lo = xr[0];                                  // vpfits.py:250
+            d.c_hi = xr[P - 1];
+            const double sigma_max = (xr[P - 1] - xr[0]) / 2.0;                       // vpfits.py:320
+            d.w_max = (mode == VAMP_GAUSS3) ? sigma_max : sigma_max * 2 * std::sqrt(2 * std::log(2.0));   // :326
+        }
+        if (!(d.c_hi > d.c_lo) || !(d.w_max > 0)) return fail(VAMP_ERR_ARG, "vamp_set_regions: empty prior range");
+        d.lp_c = -std::log(d.c_hi - d.c_lo);
+        d.lp_w = -std::log(d.w_max);
+        if (mode == VAMP_NBZ3) {
+            d.l_fixed = nbz[4 * r + 0];
+            d.line = nbz[4 * r + 1];
+            d.x_origin = nbz[4 * r + 2];
+            d.x_scale = nbz[4 * r + 3];
+        }
+        double nc = 0.0;
+        if (include_norm && !sample_sd) {
+            for (long long i = 0; i < P; ++i) {
+                const double s = noise[pix_off[r] + i];
+                nc += std::log(2.0 * M_PI * s * s);
+            }
+            nc *= -0.5;
+        }
+        d.norm_const = nc;
+        R[r] = d;
+    }
+    const long long N = pix_off[n_regions];
+    std::vector<double> wt(N);
+    for (long long i = 0; i < N; ++i) wt[i] = sample_sd ? 1.0 : 1.0 / noise[i];
+    HIP_TRY(hipMalloc(&c->x_d, N * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->f_d, N * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->wt_d, N * sizeof(double)));
+    HIP_TRY(hipMemcpy(c->x_d, x, N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->f_d, flux, N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->wt_d, wt.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    if (c->f32) {
+        std::vector<float> t(N);
+        HIP_TRY(hipMalloc(&c->xf_d, N * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->ff_d, N * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->wtf_d, N * sizeof(float)));
+        for (long long i = 0; i < N; ++i) t[i] = (float)x[i];
+        HIP_TRY(hipMemcpy(c->xf_d, t.data(), N * sizeof(float), hipMemcpyHostToDevice));
+        for (long long i = 0; i < N; ++i) t[i] = (float)flux[i];
+        HIP_TRY(hipMemcpy(c->ff_d, t.data(), N * sizeof(float), hipMemcpyHostToDevice));
+        for (long long i = 0; i < N; ++i) t[i] = (float)wt[i];
+        HIP_TRY(hipMemcpy(c->wtf_d, t.data(), N * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&c->regions_d, n_regions * sizeof(RegionDev)));
+    HIP_TRY(hipMemcpy(c->regions_d, R.data(), n_regions * sizeof(RegionDev), hipMemcpyHostToDevice));
+    c->regions_h = R;
+    c->n_regions = n_regions;
+    c->n_pix = N;
+    return VAMP_OK;
+}
+
+int vamp_region_ndim(vamp_ctx* c, int region, int* ndim) {
+    if (!c || !ndim) return fail(VAMP_ERR_ARG, "vamp_region_ndim: NULL argument");
+    if (region < 0 || region >= c->n_regions) return fail(VAMP_ERR_ARG, "vamp_region_ndim: no such region");
+    *ndim = c->regions_h[region].D;
+    return VAMP_OK;
+}
+
+int vamp_lnprob(vamp_ctx* c, int region, int64_t W, const double* theta, double* lnprob, double* chi2) {
+    if (!c || !theta || !lnprob) return fail(VAMP_ERR_ARG, "vamp_lnprob: NULL argument");
+    if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_lnprob: call vamp_set_regions first");
+    if (region < 0 || region >= c->n_regions) return fail(VAMP_ERR_ARG, "vamp_lnprob: no such region");
+    if (W <= 0) return fail(VAMP_ERR_ARG, "vamp_lnprob: W must be positive");
+    HIP_TRY(hipSetDevice(c->device));
+    const int D = c->regions_h[region].D;
+    double *th_d = nullptr, *lp_d = nullptr, *ch_d = nullptr;
+    HIP_TRY(hipMalloc(&th_d, (size_t)W * D * sizeof(double)));
+    HIP_TRY(hipMalloc(&lp_d, (size_t)W * sizeof(double)));
+    if (chi2) HIP_TRY(hipMalloc(&ch_d, (size_t)W * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(th_d, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = (unsigned)((W + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    if (c->f32)
+        hipLaunchKernelGGL((k_lnprob<true>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region, c->pix(), (long long)W,
+                           th_d, lp_d, ch_d);
+    else
+        hipLaunchKernelGGL((k_lnprob<false>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region, c->pix(), (long long)W,
+                           th_d, lp_d, ch_d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(lnprob, lp_d, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (chi2) HIP_TRY(hipMemcpyAsync(chi2, ch_d, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(th_d);
+    (void)hipFree(lp_d);
+    if (ch_d) (void)hipFree(ch_d);
+    return VAMP_OK;
+}
+
+int vamp_model(vamp_ctx* c, int region, const double* theta1, double* tau_comp, double* flux_model) {
+    if (!c || !theta1) return fail(VAMP_ERR_ARG, "vamp_model: NULL argument");
+    if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_model: call vamp_set_regions first");
+    if (region < 0 || region >= c->n_regions) return fail(VAMP_ERR_ARG, "vamp_model: no such region");
+    HIP_TRY(hipSetDevice(c->device));
+    const RegionDev& R = c->regions_h[region];
+    double *th_d = nullptr, *tau_d = nullptr, *fl_d = nullptr;
+    HIP_TRY(hipMalloc(&th_d, R.D * sizeof(double)));
+    if (tau_comp) HIP_TRY(hipMalloc(&tau_d, (size_t)R.K * R.P * sizeof(double)));
+    if (flux_model) HIP_TRY(hipMalloc(&fl_d, (size_t)R.P * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(th_d, theta1, R.D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = (unsigned)((R.P + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_model, dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region, c->pix(), th_d, tau_d, fl_d);
+    HIP_TRY(hipGetLastError());
+    if (tau_comp) HIP_TRY(hipMemcpyAsync(tau_comp, tau_d, (size_t)R.K * R.P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (flux_model) HIP_TRY(hipMemcpyAsync(flux_model, fl_d, (size_t)R.P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(th_d);
+    if (tau_d) (void)hipFree(tau_d);
+    if (fl_d) (void)hipFree(fl_d);
+    return VAMP_OK;
+}
+
+int vamp_wofz_re(vamp_ctx* c, int64_t n, const double* x, const double* y, double* re_w) {
+    if (!c || !x || !y || !re_w || n <= 0) return fail(VAMP_ERR_ARG, "vamp_wofz_re: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    double *x_d = nullptr, *y_d = nullptr, *o_d = nullptr;
+    HIP_TRY(hipMalloc(&x_d, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&y_d, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&o_d, n * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(x_d, x, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(y_d, y, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    if (c->f32) hipLaunchKernelGGL((k_wofz<true>), dim3(grid), dim3(BLOCK), 0, c->stream, (long long)n, x_d, y_d, o_d);
+    else hipLaunchKernelGGL((k_wofz<false>), dim3(grid), dim3(BLOCK), 0, c->stream, (long long)n, x_d, y_d, o_d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(re_w, o_d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(x_d);
+    (void)hipFree(y_d);
+    (void)hipFree(o_d);
+    return VAMP_OK;
+}
+
+int vamp_sampler_bind_state(vamp_ctx* c, void* X_dev, void* lnp_dev) {
+    if (!c || !X_dev || !lnp_dev) return fail(VAMP_ERR_ARG, "vamp_sampler_bind_state: NULL argument");
+    free_sampler(c);
+    c->X_d = (double*)X_dev;
+    c->lnp_d = (double*)lnp_dev;
+    c->X_ext = true;
+    return VAMP_OK;
+}
+
+int vamp_sampler_init(vamp_ctx* c, int64_t W, const double* theta0, uint64_t seed, double a, int32_t split_block) {
+    if (!c || !theta0) return fail(VAMP_ERR_ARG, "vamp_sampler_init: NULL argument");
+    if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_sampler_init: call vamp_set_regions first");
+    if (W < 2 || (W & 1)) return fail(VAMP_ERR_ARG, "vamp_sampler_init: W must be even and >= 2");
+    if (split_block < 2 || (split_block & 1) || W % split_block) return fail(VAMP_ERR_ARG, "vamp_sampler_init: split_block must be even and divide W");
+    if (!(a > 1.0)) return fail(VAMP_ERR_ARG, "vamp_sampler_init: a must be > 1");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    long long tt = 0;
+    for (int r = 0; r < c->n_regions; ++r) {
+        c->regions_h[r].theta_off = tt;
+        c->regions_h[r].walker_off = (long long)r * W;
+        tt += (long long)W * c->regions_h[r].D;
+    }
+    HIP_TRY(hipMemcpy(c->regions_d, c->regions_h.data(), c->n_regions * sizeof(RegionDev), hipMemcpyHostToDevice));
+    const bool ext = c->X_ext && c->X_d;
+    if (!ext) free_sampler(c);
+    if (c->nacc_d) { (void)hipFree(c->nacc_d); c->nacc_d = nullptr; }
+    c->W = W;
+    c->total_theta = tt;
+    c->total_walkers = (long long)c->n_regions * W;
+    c->split_block = split_block;
+    c->a = a;
+    c->seed = seed;
+    c->step = 0;
+    if (!ext) {
+        c->X_ext = false;
+        HIP_TRY(hipMalloc(&c->X_d, tt * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->lnp_d, c->total_walkers * sizeof(double)));
+    }
+    HIP_TRY(hipMalloc(&c->nacc_d, c->total_walkers * sizeof(long long)));
+    HIP_TRY(hipMemsetAsync(c->nacc_d, 0, c->total_walkers * sizeof(long long), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->X_d, theta0, tt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // initial log-posteriors of every walker
+    for (int r = 0; r < c->n_regions; ++r) {
+        const RegionDev& R = c->regions_h[r];
+        const unsigned grid = (unsigned)((W + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+        if (c->f32)
+            hipLaunchKernelGGL((k_lnprob<true>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r, c->pix(), (long long)W,
+                               c->X_d + R.theta_off, c->lnp_d + R.walker_off, nullptr);
+        else
+            hipLaunchKernelGGL((k_lnprob<false>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r, c->pix(), (long long)W,
+                               c->X_d + R.theta_off, c->lnp_d + R.walker_off, nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->shard_rank = 0;
+    c->shard_world = 1;
+    c->slot_begin = 0;
+    c->slot_end = c->total_walkers / 2;
+    c->sampler_ready = true;
+    return VAMP_OK;
+}
+
+int vamp_sampler_set_shard(vamp_ctx* c, int rank, int world, int64_t* own_begin, int64_t* own_end) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: ctx is NULL");
+    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_set_shard: call vamp_sampler_init first");
+    if (world < 1 || rank < 0 || rank >= world) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: bad rank/world");
+    if (c->n_regions != 1) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: walker sharding is for single-region contexts (shard regions across devices otherwise)");
+    const long long chunks = c->W / c->split_block;
+    if (chunks % world) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: W/split_block must be a multiple of world");
+    const long long cpr = chunks / world;
+    c->shard_rank = rank;
+    c->shard_world = world;
+    c->slot_begin = rank * cpr * (c->split_block / 2);
+    c->slot_end = (rank + 1) * cpr * (c->split_block / 2);
+    if (own_begin) *own_begin = rank * cpr * c->split_block;
+    if (own_end) *own_end = (rank + 1) * cpr * c->split_block;
+    return VAMP_OK;
+}
+
+int vamp_sampler_state_ptrs(vamp_ctx* c, void** X_dev, void** lnp_dev, int64_t* total_theta, int64_t* total_walkers) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_sampler_state_ptrs: ctx is NULL");
+    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_state_ptrs: call vamp_sampler_init first");
+    if (X_dev) *X_dev = c->X_d;
+    if (lnp_dev) *lnp_dev = c->lnp_d;
+    if (total_theta) *total_theta = c->total_theta;
+    if (total_walkers) *total_walkers = c->total_walkers;
+    return VAMP_OK;
+}
+
+int vamp_sampler_half_step(vamp_ctx* c, int half) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step: ctx is NULL");
+    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_half_step: call vamp_sampler_init first");
+    if (half != 0 && half != 1) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step: half must be 0 or 1");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = launch_half(c, half, false, 0, 0);
+    if (rc) return rc;
+    if (half == 1) c->step += 1;
+    return VAMP_OK;
+}
+
+int vamp_sampler_half_step_ext(vamp_ctx* c, int region, int64_t n, const int32_t* active_idx, const int32_t* partner_idx,
+                               const double* zz, const double* logu) {
+    if (!c || !active_idx || !partner_idx || !zz || !logu) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_ext: NULL argument");
+    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_half_step_ext: call vamp_sampler_init first");
+    if (region < 0 || region >= c->n_regions) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_ext: no such region");
+    if (n <= 0 || n > c->W) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_ext: bad n");
+    // validate on the host: a wild index would be an out-of-bounds device access
+    std::vector<char> is_active(c->W, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (active_idx[i] < 0 || active_idx[i] >= c->W || partner_idx[i] < 0 || partner_idx[i] >= c->W)
+            return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_ext: walker index out of range");
+        if (is_active[active_idx[i]]) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_ext: duplicate active walker");
+        is_active[active_idx[i]] = 1;
+        if (!(zz[i] > 0.0)) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_ext: stretch factor must be positive");
+    }
+    for (int64_t i = 0; i < n; ++i)
+        if (is_active[partner_idx[i]]) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_ext: partner must belong to the frozen complement");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->ext_cap < n) {
+        for (void* p : {(void*)c->ext_act_d, (void*)c->ext_par_d, (void*)c->ext_z_d, (void*)c->ext_lu_d})
+            if (p) (void)hipFree(p);
+        c->ext_cap = 0;
+        HIP_TRY(hipMalloc(&c->ext_act_d, n * sizeof(int)));
+        HIP_TRY(hipMalloc(&c->ext_par_d, n * sizeof(int)));
+        HIP_TRY(hipMalloc(&c->ext_z_d, n * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->ext_lu_d, n * sizeof(double)));
+        c->ext_cap = n;
+    }
+    HIP_TRY(hipMemcpyAsync(c->ext_act_d, active_idx, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ext_par_d, partner_idx, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ext_z_d, zz, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ext_lu_d, logu, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = launch_half(c, 0, true, region, n);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VAMP_OK;
+}
+
+int vamp_sampler_run(vamp_ctx* c, int64_t n_steps, int thin, double* chain, double* lnprob_chain, int64_t* n_accept,
+                     double* seconds) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_sampler_run: ctx is NULL");
+    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_run: call vamp_sampler_init first");
+    if (n_steps < 0 || thin < 1) return fail(VAMP_ERR_ARG, "vamp_sampler_run: n_steps >= 0 and thin >= 1 required");
+    if (c->shard_world != 1) return fail(VAMP_ERR_STATE, "vamp_sampler_run: sharded contexts are stepped by the host (half_step + all-gather)");
+    HIP_TRY(hipSetDevice(c->device));
+    const long long n_keep = n_steps / thin;
+    double *chain_d = nullptr, *lchain_d = nullptr;
+    if (chain && n_keep) HIP_TRY(hipMalloc(&chain_d, (size_t)n_keep * c->total_theta * sizeof(double)));
+    if (lnprob_chain && n_keep) HIP_TRY(hipMalloc(&lchain_d, (size_t)n_keep * c->total_walkers * sizeof(double)));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    long long kept = 0;
+    for (long long it = 0; it < n_steps; ++it) {
+        for (int half = 0; half < 2; ++half) {
+            int rc = launch_half(c, half, false, 0, 0);
+            if (rc) return rc;
+        }
+        c->step += 1;
+        if ((it + 1) % thin == 0 && kept < n_keep) {
+            if (chain_d)
+                HIP_TRY(hipMemcpyAsync(chain_d + kept * c->total_theta, c->X_d, c->total_theta * sizeof(double),
+                                       hipMemcpyDeviceToDevice, c->stream));
+            if (lchain_d)
+                HIP_TRY(hipMemcpyAsync(lchain_d + kept * c->total_walkers, c->lnp_d, c->total_walkers * sizeof(double),
+                                       hipMemcpyDeviceToDevice, c->stream));
+            ++kept;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (chain_d) {
+        HIP_TRY(hipMemcpy(chain, chain_d, (size_t)n_keep * c->total_theta * sizeof(double), hipMemcpyDeviceToHost));
+        (void)hipFree(chain_d);
+    }
+    if (lchain_d) {
+        HIP_TRY(hipMemcpy(lnprob_chain, lchain_d, (size_t)n_keep * c->total_walkers * sizeof(double), hipMemcpyDeviceToHost));
+        (void)hipFree(lchain_d);
+    }
+    if (n_accept) HIP_TRY(hipMemcpy(n_accept, c->nacc_d, c->total_walkers * sizeof(long long), hipMemcpyDeviceToHost));
+    return VAMP_OK;
+}
+
+int vamp_sampler_get_state(vamp_ctx* c, double* theta, double* lnprob, int64_t* n_accept, int64_t* step) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_sampler_get_state: ctx is NULL");
+    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_get_state: call vamp_sampler_init first");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (theta) HIP_TRY(hipMemcpy(theta, c->X_d, c->total_theta * sizeof(double), hipMemcpyDeviceToHost));
+    if (lnprob) HIP_TRY(hipMemcpy(lnprob, c->lnp_d, c->total_walkers * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_accept) HIP_TRY(hipMemcpy(n_accept, c->nacc_d, c->total_walkers * sizeof(long long), hipMemcpyDeviceToHost));
+    if (step) *step = c->step;
+    return VAMP_OK;
+}
+
+int vamp_sampler_set_state(vamp_ctx* c, const double* theta, const double* lnprob, int64_t step) {
+    if (!c || !theta || !lnprob) return fail(VAMP_ERR_ARG, "vamp_sampler_set_state: NULL argument");
+    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_set_state: call vamp_sampler_init first");
+    if (step < 0) return fail(VAMP_ERR_ARG, "vamp_sampler_set_state: step must be >= 0");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->X_d, theta, c->total_theta * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->lnp_d, lnprob, c->total_walkers * sizeof(double), hipMemcpyHostToDevice));
+    c->step = step;
+    return VAMP_OK;
+}
+
+int vamp_kernel_timing(vamp_ctx* c, int enable, double* total_ms, int64_t* launches) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_kernel_timing: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = flush_timing(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->timing_ms;
+    if (launches) *launches = c->timing_launches;
+    c->timing_ms = 0.0;
+    c->timing_launches = 0;
+    c->timing = enable != 0;
+    return VAMP_OK;
+}
+
+}  // extern "C"

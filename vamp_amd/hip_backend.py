@@ -1,0 +1,236 @@
+"""Thin, numpy-typed wrapper over the C ABI (one object per ``vamp_ctx``).
+
+This is the only module that touches ctypes pointers; ``vpfits.VPfit`` and the ensemble driver
+are written against it.  Every call lands in hand-written HIP (vamp_amd/csrc/vamp_hip.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+MODE_GAUSS3, MODE_VOIGT4, MODE_NBZ3 = 0, 1, 2
+Q_OF_MODE = {MODE_GAUSS3: 3, MODE_VOIGT4: 4, MODE_NBZ3: 3}
+F64, F32 = 0, 1
+WOFZ_ACCURATE, WOFZ_HUMLICEK_W4 = 0, 1
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.c_double_p) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    n = C.c_int(0)
+    _lib.check(_lib.load().vamp_device_count(C.byref(n)))
+    return n.value
+
+
+def default_split_block(W, world=1):
+    """Largest even divisor of W that is <= 1024 and keeps W/block a multiple of ``world``."""
+    for b in range(min(W, 1024), 1, -1):
+        if b % 2 == 0 and W % b == 0 and (W // b) % world == 0:
+            return b
+    raise ValueError(f"no valid split block for W={W}, world={world}")
+
+
+class HipContext:
+    """One device context: regions + (optionally) an ensemble sampler."""
+
+    def __init__(self, device=0, dtype=F64, wofz_kind=None):
+        self._lib = _lib.load()
+        if wofz_kind is None:
+            wofz_kind = WOFZ_ACCURATE if dtype == F64 else WOFZ_HUMLICEK_W4
+        h = C.c_void_p()
+        _lib.check(self._lib.vamp_ctx_create(C.byref(h), device, dtype, wofz_kind))
+        self._h = h
+        self.device = device
+        self.dtype = dtype
+        self.n_regions = 0
+        self.ndims = []
+        self.W = 0
+
+    # -- lifetime ------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.vamp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, stream_ptr):
+        _lib.check(self._lib.vamp_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        _lib.check(self._lib.vamp_ctx_synchronize(self._h))
+
+    # -- data ----------------------------------------------------------------------------
+    def set_regions(self, xs, fluxes, noises, n_comp, mode=MODE_VOIGT4, sample_sd=False, include_norm=False,
+                    bounds=None, nbz=None):
+        """xs/fluxes/noises: lists of 1-D arrays (one per region); n_comp: int or list."""
+        if isinstance(xs, np.ndarray) and xs.ndim == 1:
+            xs, fluxes, noises = [xs], [fluxes], [noises]
+        R = len(xs)
+        if np.isscalar(n_comp):
+            n_comp = [int(n_comp)] * R
+        off = np.zeros(R + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(x) for x in xs])
+        x = _f64(np.concatenate([_f64(a) for a in xs]))
+        f = _f64(np.concatenate([_f64(a) for a in fluxes]))
+        n = _f64(np.concatenate([_f64(a) for a in noises]))
+        nc = np.ascontiguousarray(n_comp, dtype=np.int32)
+        b = _f64(bounds).reshape(R, 4) if bounds is not None else None
+        z = _f64(nbz).reshape(R, 4) if nbz is not None else None
+        _lib.check(self._lib.vamp_set_regions(
+            self._h, R, off.ctypes.data_as(_lib.c_int64_p), _dp(x), _dp(f), _dp(n),
+            nc.ctypes.data_as(_lib.c_int32_p), int(mode), int(bool(sample_sd)), int(bool(include_norm)), _dp(b), _dp(z)))
+        self.n_regions = R
+        self.mode = mode
+        self.ndims = []
+        for r in range(R):
+            d = C.c_int(0)
+            _lib.check(self._lib.vamp_region_ndim(self._h, r, C.byref(d)))
+            self.ndims.append(d.value)
+        self.n_pix = [len(a) for a in xs]
+        self.n_comp = [int(k) for k in n_comp]
+
+    # -- evaluation ----------------------------------------------------------------------
+    def lnprob(self, theta, region=0, return_chi2=False):
+        theta = _f64(theta)
+        if theta.ndim == 1:
+            theta = theta[None, :]
+        W, D = theta.shape
+        if D != self.ndims[region]:
+            raise ValueError(f"theta has {D} dims, region {region} needs {self.ndims[region]}")
+        out = np.empty(W)
+        chi = np.empty(W) if return_chi2 else None
+        _lib.check(self._lib.vamp_lnprob(self._h, region, W, _dp(theta), _dp(out), _dp(chi)))
+        return (out, chi) if return_chi2 else out
+
+    def model(self, theta1, region=0):
+        theta1 = _f64(theta1).ravel()
+        if theta1.size != self.ndims[region]:
+            raise ValueError("theta1 has the wrong length")
+        K, P = self.n_comp[region], self.n_pix[region]
+        tau = np.empty((K, P))
+        flux = np.empty(P)
+        _lib.check(self._lib.vamp_model(self._h, region, _dp(theta1), _dp(tau), _dp(flux)))
+        return tau, flux
+
+    def wofz_re(self, x, y):
+        x = _f64(x).ravel()
+        y = _f64(y).ravel()
+        out = np.empty_like(x)
+        _lib.check(self._lib.vamp_wofz_re(self._h, x.size, _dp(x), _dp(y), _dp(out)))
+        return out
+
+    # -- sampler -------------------------------------------------------------------------
+    def sampler_bind_state(self, X_ptr, lnp_ptr):
+        _lib.check(self._lib.vamp_sampler_bind_state(self._h, C.c_void_p(X_ptr), C.c_void_p(lnp_ptr)))
+
+    def sampler_init(self, theta0, seed=0, a=2.0, split_block=None):
+        """theta0: array [W, D] (single region) or list of [W, D_r] arrays."""
+        blocks = [theta0] if isinstance(theta0, np.ndarray) else list(theta0)
+        if len(blocks) != self.n_regions:
+            raise ValueError("one theta0 block per region is required")
+        W = blocks[0].shape[0]
+        for r, b in enumerate(blocks):
+            if b.shape != (W, self.ndims[r]):
+                raise ValueError(f"theta0[{r}] must have shape ({W}, {self.ndims[r]})")
+        if split_block is None:
+            split_block = default_split_block(W)
+        flat = _f64(np.concatenate([_f64(b).ravel() for b in blocks]))
+        _lib.check(self._lib.vamp_sampler_init(self._h, W, _dp(flat), C.c_uint64(seed & (2**64 - 1)), float(a), int(split_block)))
+        self.W = W
+        self.split_block = split_block
+        self.total_theta = flat.size
+        self.total_walkers = W * self.n_regions
+
+    def sampler_set_shard(self, rank, world):
+        b, e = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.vamp_sampler_set_shard(self._h, rank, world, C.byref(b), C.byref(e)))
+        return b.value, e.value
+
+    def sampler_state_ptrs(self):
+        X, L = C.c_void_p(), C.c_void_p()
+        tt, tw = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.vamp_sampler_state_ptrs(self._h, C.byref(X), C.byref(L), C.byref(tt), C.byref(tw)))
+        return X.value, L.value, tt.value, tw.value
+
+    def half_step(self, half):
+        _lib.check(self._lib.vamp_sampler_half_step(self._h, int(half)))
+
+    def half_step_ext(self, active, partner, zz, logu, region=0):
+        a = np.ascontiguousarray(active, dtype=np.int32)
+        p = np.ascontiguousarray(partner, dtype=np.int32)
+        z = _f64(zz)
+        u = _f64(logu)
+        _lib.check(self._lib.vamp_sampler_half_step_ext(
+            self._h, region, a.size, a.ctypes.data_as(_lib.c_int32_p), p.ctypes.data_as(_lib.c_int32_p), _dp(z), _dp(u)))
+
+    def _split(self, flat, per_walker):
+        """flat [.., total] -> list of per-region arrays"""
+        out, o = [], 0
+        for r in range(self.n_regions):
+            n = self.W * (self.ndims[r] if not per_walker else 1)
+            blk = flat[..., o:o + n]
+            out.append(blk.reshape(flat.shape[:-1] + ((self.W, self.ndims[r]) if not per_walker else (self.W,))))
+            o += n
+        return out
+
+    def run(self, n_steps, thin=1, store_chain=True):
+        """Returns dict(chain, lnprob, n_accept, seconds); chain/lnprob are arrays for a single
+        region ([n_keep, W, D] / [n_keep, W]) or lists of such arrays."""
+        n_keep = n_steps // thin
+        chain = np.empty((n_keep, self.total_theta)) if store_chain else None
+        lchain = np.empty((n_keep, self.total_walkers)) if store_chain else None
+        nacc = np.empty(self.total_walkers, dtype=np.int64)
+        sec = C.c_double(0.0)
+        _lib.check(self._lib.vamp_sampler_run(self._h, n_steps, thin, _dp(chain), _dp(lchain),
+                                              nacc.ctypes.data_as(_lib.c_int64_p), C.byref(sec)))
+        res = {"seconds": sec.value, "n_accept": nacc if self.n_regions == 1 else self._split(nacc, True)}
+        if store_chain:
+            ch, lc = self._split(chain, False), self._split(lchain, True)
+            res["chain"] = ch[0] if self.n_regions == 1 else ch
+            res["lnprob"] = lc[0] if self.n_regions == 1 else lc
+        return res
+
+    def get_state(self):
+        th = np.empty(self.total_theta)
+        lp = np.empty(self.total_walkers)
+        na = np.empty(self.total_walkers, dtype=np.int64)
+        st = C.c_int64(0)
+        _lib.check(self._lib.vamp_sampler_get_state(self._h, _dp(th), _dp(lp), na.ctypes.data_as(_lib.c_int64_p), C.byref(st)))
+        X = self._split(th, False)
+        L = self._split(lp, True)
+        if self.n_regions == 1:
+            return X[0], L[0], na, st.value
+        return X, L, self._split(na, True), st.value
+
+    def set_state(self, theta, lnprob, step):
+        blocks = [theta] if isinstance(theta, np.ndarray) else list(theta)
+        lps = [lnprob] if isinstance(lnprob, np.ndarray) else list(lnprob)
+        th = _f64(np.concatenate([_f64(b).ravel() for b in blocks]))
+        lp = _f64(np.concatenate([_f64(b).ravel() for b in lps]))
+        _lib.check(self._lib.vamp_sampler_set_state(self._h, _dp(th), _dp(lp), int(step)))
+
+    def kernel_timing(self, enable=True):
+        ms = C.c_double(0.0)
+        n = C.c_int64(0)
+        _lib.check(self._lib.vamp_kernel_timing(self._h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
