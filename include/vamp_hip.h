@@ -98,6 +98,12 @@ int vamp_lnprob(vamp_ctx* ctx, int region, int64_t W, const double* theta, doubl
 int vamp_model(vamp_ctx* ctx, int region, const double* theta1, double* tau_comp,
                double* flux_model);
 
+/* The per-line records the kernels stage in LDS for one parameter vector, rec[K*5] =
+ * {centroid, x-scale, damping y, tau scale, pole factor} per component, and the log-prior: test
+ * hook for the parameter maps of physics.py:6-27,116-134 / vpfits.py:79-88 and the priors of
+ * vpfits.py:239-252,283-297. */
+int vamp_line_records(vamp_ctx* ctx, int region, const double* theta1, double* rec, double* lnprior);
+
 /* Device evaluation of Re w(x + i y) with the ctx's wofz_kind (test hook for the in-register
  * Faddeeva evaluator; the profile of vpfits.py:57-76 is built on it). */
 int vamp_wofz_re(vamp_ctx* ctx, int64_t n, const double* x, const double* y, double* re_w);

@@ -64,6 +64,38 @@ def test_lnprob_matches_golden(hip_ctx):
         assert np.allclose(flux, g[name + "_flux0"], rtol=1e-12, atol=1e-300), name
 
 
+def test_line_records_and_prior_match_oracle(hip_ctx):
+    """Device-side parameter maps ((N,b,z) -> native, physics.py:6-27,116-134) and log-prior
+    (vpfits.py:239-252,283-297) against the oracle, per walker."""
+    g = load_golden("lnprob_cases.npz")
+    for name in ("H1215_r0_K2_m2_sd0", "H1215_r0_K4_m1_sd0", "H1215_r1_K2_m0_sd0", "H1215_r0_K2_m1_sd1"):
+        x, f, n, K, mode, sd, nbz = _case(g, name)
+        hip_ctx.set_regions(x, f, n, K, mode=mode, sample_sd=sd, nbz=None if nbz is None else nbz[None, :])
+        r = vo.Region(x=x, flux=f, noise=n, n_comp=K, mode=mode, sample_sd=sd)
+        if nbz is not None:
+            r.l_fixed, r.line, r.x_origin, r.x_scale = [float(v) for v in nbz]
+        th = g[name + "_theta"]
+        for w in range(th.shape[0]):
+            rec, lp = hip_ctx.line_records(th[w])
+            want_lp = g[name + "_lnprior"][w]
+            if np.isfinite(want_lp):
+                assert abs(lp - want_lp) <= 1e-12 * max(1.0, abs(want_lp)), (name, w)
+            else:
+                assert lp == -np.inf or np.isnan(lp), (name, w)
+            if not np.all(np.isfinite(th[w])):
+                continue
+            with np.errstate(all="ignore"):
+                comps = vo.native_components(r, th[w])
+            for k, comp in enumerate(comps):
+                if mode == vo.MODE_GAUSS3:
+                    a, c, s = comp
+                    want = (c, 1.0 / s if s != 0 else np.inf, 0.0, a)
+                else:
+                    a, c, L, G = comp
+                    want = (c, 2 * vo.SQRT_LN2 / G, L * vo.SQRT_LN2 / G, a * L * np.sqrt(np.pi) * vo.SQRT_LN2 / G)
+                assert np.allclose(rec[k, :4], want, rtol=1e-13, atol=0), (name, w, k, rec[k], want)
+
+
 def test_lnprob_include_norm_and_bounds(hip_ctx):
     g = load_golden("lnprob_cases.npz")
     name = "H1215_r1_K4_m1_sd0"

@@ -31,6 +31,7 @@ SIGNATURES = {
     "vamp_region_ndim": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "vamp_lnprob": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p, c_double_p, c_double_p]),
     "vamp_model": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "vamp_line_records": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "vamp_wofz_re": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
     "vamp_sampler_init": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_uint64, C.c_double, C.c_int32]),
     "vamp_sampler_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int64_p, c_int64_p]),

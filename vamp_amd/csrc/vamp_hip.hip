@@ -97,16 +97,20 @@ __device__ __forceinline__ double uniform_logp(double v, double lo, double hi, d
 }
 
 // Turn theta (in LDS) into line records + prior.  Returns log-prior on every lane.
+// MODE is a compile-time parameter: one specialised kernel per parameterisation, no mode
+// branches in the staging code or in the pixel loop.
+template <int MODE>
 __device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, int lane, bool want_f32) {
     double lp = 0.0;
     const int K = R.K;
+    constexpr int Q = (MODE == VAMP_VOIGT4) ? 4 : 3;
     if (lane < K) {
-        const double* t = &L.theta[R.q * lane];
+        const double* t = &L.theta[Q * lane];
         double a, c, Lw = 0.0, G = 0.0, sg = 0.0;
-        if (R.mode == VAMP_GAUSS3) {
+        if constexpr (MODE == VAMP_GAUSS3) {
             a = t[0]; c = t[1]; sg = t[2];
             lp = xexp_logp(a) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) + uniform_logp(sg, 0.0, R.w_max, R.lp_w);
-        } else if (R.mode == VAMP_VOIGT4) {
+        } else if constexpr (MODE == VAMP_VOIGT4) {
             a = t[0]; c = t[1]; Lw = t[2]; G = t[3];
             lp = xexp_logp(a) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) +
                  uniform_logp(Lw, 0.0, R.w_max, R.lp_w) + uniform_logp(G, 0.0, R.w_max, R.lp_w);
@@ -120,7 +124,7 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, in
         }
         LineRec rec;
         rec.c = c;
-        if (R.mode == VAMP_GAUSS3) {
+        if constexpr (MODE == VAMP_GAUSS3) {
             rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0;
         } else {
             rec.s = 2.0 * SQRT_LN2 / G;
@@ -139,7 +143,7 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, in
     }
     lp = wave_sum(lp);
     __builtin_amdgcn_wave_barrier();
-    if (R.mode != VAMP_GAUSS3 && !want_f32) {
+    if (MODE != VAMP_GAUSS3 && !want_f32) {
         for (int e = lane; e < K * vamp::DTAB_N; e += 64) {
             const int k = e / vamp::DTAB_N, n = e % vamp::DTAB_N;
             L.dtab[k][n] = vamp::core_dtab_entry(n, L.line[k].y);
@@ -150,15 +154,16 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, in
 }
 
 // chi^2 sweep, fp64 pixel arithmetic.  Returns sum over the wave's pixels of ((f-m) w)^2.
+template <int MODE>
 __device__ __forceinline__ double sweep_f64(const RegionDev& R, const WaveLds& L, const double* __restrict__ x,
                                             const double* __restrict__ f, const double* __restrict__ wt, int lane) {
     double chi = 0.0;
     const int K = R.K, P = R.P;
-    const bool gauss = (R.mode == VAMP_GAUSS3);
+    constexpr bool gauss = (MODE == VAMP_GAUSS3);
     for (int i = lane; i < P; i += 64) {
         const double xi = x[i];
         double tau = 0.0;
-        if (gauss) {
+        if constexpr (gauss) {
             for (int k = 0; k < K; ++k) {
                 const double u = (xi - L.line[k].c) * L.line[k].s;
                 tau += L.line[k].amp * exp(-0.5 * (u * u));
@@ -178,15 +183,16 @@ __device__ __forceinline__ double sweep_f64(const RegionDev& R, const WaveLds& L
 }
 
 // fp32 pixel arithmetic (Humlicek W4), chi^2 accumulated in fp64 (SURVEY section 7 hard parts).
+template <int MODE>
 __device__ __forceinline__ double sweep_f32(const RegionDev& R, const WaveLds& L, const float* __restrict__ x,
                                             const float* __restrict__ f, const float* __restrict__ wt, int lane) {
     double chi = 0.0;
     const int K = R.K, P = R.P;
-    const bool gauss = (R.mode == VAMP_GAUSS3);
+    constexpr bool gauss = (MODE == VAMP_GAUSS3);
     for (int i = lane; i < P; i += 64) {
         const float xi = x[i];
         float tau = 0.0f;
-        if (gauss) {
+        if constexpr (gauss) {
             for (int k = 0; k < K; ++k) {
                 const float u = (xi - L.linef[k][0]) * L.linef[k][1];
                 tau += L.linef[k][3] * __expf(-0.5f * (u * u));
@@ -219,16 +225,16 @@ struct PixPtrs {
     const float* xf; const float* ff; const float* wtf;       // fp32 copies (may be null)
 };
 
-template <bool F32>
+template <bool F32, int MODE>
 __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WaveLds& L, const PixPtrs& px, int lane, double* chi_out) {
-    const double lp = stage_lines(R, L, lane, F32);
+    const double lp = stage_lines<MODE>(R, L, lane, F32);
     if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
         if (chi_out) *chi_out = __builtin_nan("");
         return NEG_INF;
     }
     double ssum;
-    if (F32) ssum = sweep_f32(R, L, px.xf + R.pix_off, px.ff + R.pix_off, px.wtf + R.pix_off, lane);
-    else ssum = sweep_f64(R, L, px.x + R.pix_off, px.f + R.pix_off, px.wt + R.pix_off, lane);
+    if constexpr (F32) ssum = sweep_f32<MODE>(R, L, px.xf + R.pix_off, px.ff + R.pix_off, px.wtf + R.pix_off, lane);
+    else ssum = sweep_f64<MODE>(R, L, px.x + R.pix_off, px.f + R.pix_off, px.wt + R.pix_off, lane);
     if (chi_out) *chi_out = ssum;
     double v = lp + loglike_from_sum(R, L, ssum);
     if (v != v) v = NEG_INF;                 // NaN -> -inf (emcee convention)
@@ -238,7 +244,7 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WaveLds& L, co
 // ---------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------
-template <bool F32>
+template <bool F32, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
                                                   long long W, const double* __restrict__ theta,
                                                   double* __restrict__ lnprob, double* __restrict__ chi2) {
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(BLOCK) void k_lnprob(const RegionDev* __restrict__ 
     for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[w * R.D + d];
     __builtin_amdgcn_wave_barrier();
     double chi;
-    const double v = wave_lnprob<F32>(R, L, px, lane, &chi);
+    const double v = wave_lnprob<F32, MODE>(R, L, px, lane, &chi);
     if (lane == 0) {
         lnprob[w] = v;
         if (chi2) chi2[w] = chi;
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(BLOCK) void k_lnprob(const RegionDev* __restrict__ 
 }
 
 // tau_k[P] and flux[P] for one parameter vector (one thread per pixel)
+template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_model(const RegionDev* __restrict__ regions, int region, PixPtrs px,
                                                  const double* __restrict__ theta, double* __restrict__ tau_comp,
                                                  double* __restrict__ flux_model) {
@@ -268,14 +275,14 @@ __global__ __launch_bounds__(BLOCK) void k_model(const RegionDev* __restrict__ r
     WaveLds& L = lds[wave];
     for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[d];
     __builtin_amdgcn_wave_barrier();
-    (void)stage_lines(R, L, lane, false);
+    (void)stage_lines<MODE>(R, L, lane, false);
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= R.P) return;
     const double xi = px.x[R.pix_off + i];
     double tau = 0.0;
     for (int k = 0; k < R.K; ++k) {
         double tk;
-        if (R.mode == VAMP_GAUSS3) {
+        if constexpr (MODE == VAMP_GAUSS3) {
             const double u = (xi - L.line[k].c) * L.line[k].s;
             tk = L.line[k].amp * exp(-0.5 * (u * u));
         } else {
@@ -286,6 +293,28 @@ __global__ __launch_bounds__(BLOCK) void k_model(const RegionDev* __restrict__ r
         tau += tk;
     }
     if (flux_model) flux_model[i] = exp(-tau);
+}
+
+// staged per-line records of one parameter vector (test hook for the parameter maps)
+template <int MODE>
+__global__ __launch_bounds__(64) void k_line_records(const RegionDev* __restrict__ regions, int region,
+                                                     const double* __restrict__ theta, double* __restrict__ rec,
+                                                     double* __restrict__ lnprior) {
+    __shared__ WaveLds lds[1];
+    const int lane = threadIdx.x & 63;
+    const RegionDev R = regions[region];
+    WaveLds& L = lds[0];
+    for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[d];
+    __builtin_amdgcn_wave_barrier();
+    const double lp = stage_lines<MODE>(R, L, lane, false);
+    if (lane < R.K) {
+        rec[5 * lane + 0] = L.line[lane].c;
+        rec[5 * lane + 1] = L.line[lane].s;
+        rec[5 * lane + 2] = L.line[lane].y;
+        rec[5 * lane + 3] = L.line[lane].amp;
+        rec[5 * lane + 4] = L.line[lane].pole;
+    }
+    if (lane == 0) *lnprior = lp;
 }
 
 template <bool F32>
@@ -360,7 +389,7 @@ struct SamplerDev {
 
 // One half-step of the stretch move, one wavefront per active walker.
 //   EXT = draws supplied by the host (deterministic-parity hook); else Philox in-kernel.
-template <bool F32, bool EXT>
+template <bool F32, bool EXT, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
                                                      long long ext_n, const int* __restrict__ ext_active,
                                                      const int* __restrict__ ext_partner, const double* __restrict__ ext_z,
@@ -410,7 +439,7 @@ __global__ __launch_bounds__(BLOCK) void k_half_step(SamplerDev S, PixPtrs px, u
         L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
     }
     __builtin_amdgcn_wave_barrier();
-    const double lnp_q = wave_lnprob<F32>(R, L, px, lane, nullptr);
+    const double lnp_q = wave_lnprob<F32, MODE>(R, L, px, lane, nullptr);
     const long long wg = R.walker_off + ws;
     const double lnp_s = S.lnp[wg];
     const double diff = (double)(R.D - 1) * log(z) + lnp_q - lnp_s;
@@ -441,6 +470,14 @@ int fail(int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                   \
     } while (0)
 
+// run STMT with `M` bound to the compile-time parameterisation that matches runtime `mode`
+#define VAMP_FOR_MODE(mode, STMT)                                        \
+    do {                                                                 \
+        if ((mode) == VAMP_GAUSS3) { constexpr int M = VAMP_GAUSS3; STMT; } \
+        else if ((mode) == VAMP_VOIGT4) { constexpr int M = VAMP_VOIGT4; STMT; } \
+        else { constexpr int M = VAMP_NBZ3; STMT; }                      \
+    } while (0)
+
 }  // namespace
 
 struct vamp_ctx {
@@ -452,6 +489,7 @@ struct vamp_ctx {
     hipStream_t stream = nullptr;
     // regions
     int n_regions = 0;
+    int mode = VAMP_VOIGT4;
     std::vector<RegionDev> regions_h;
     RegionDev* regions_d = nullptr;
     long long n_pix = 0;
@@ -560,18 +598,20 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     const PixPtrs px = c->pix();
     if (ext) {
         if (c->f32)
-            hipLaunchKernelGGL((k_half_step<true, true>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step, half, ext_region,
-                               ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d);
+            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_half_step<true, true, M>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+                                                      half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d));
         else
-            hipLaunchKernelGGL((k_half_step<false, true>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step, half, ext_region,
-                               ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d);
+            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_half_step<false, true, M>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+                                                      half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d));
     } else {
+        const int* ni = nullptr;
+        const double* nd = nullptr;
         if (c->f32)
-            hipLaunchKernelGGL((k_half_step<true, false>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step, half, 0, 0ll,
-                               nullptr, nullptr, nullptr, nullptr);
+            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_half_step<true, false, M>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+                                                      half, 0, 0ll, ni, ni, nd, nd));
         else
-            hipLaunchKernelGGL((k_half_step<false, false>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step, half, 0, 0ll,
-                               nullptr, nullptr, nullptr, nullptr);
+            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_half_step<false, false, M>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+                                                      half, 0, 0ll, ni, ni, nd, nd));
     }
     HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
@@ -729,6 +769,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
     HIP_TRY(hipMalloc(&c->regions_d, n_regions * sizeof(RegionDev)));
     HIP_TRY(hipMemcpy(c->regions_d, R.data(), n_regions * sizeof(RegionDev), hipMemcpyHostToDevice));
     c->regions_h = R;
+    c->mode = mode;
     c->n_regions = n_regions;
     c->n_pix = N;
     return VAMP_OK;
@@ -755,11 +796,11 @@ int vamp_lnprob(vamp_ctx* c, int region, int64_t W, const double* theta, double*
     HIP_TRY(hipMemcpyAsync(th_d, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const unsigned grid = (unsigned)((W + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     if (c->f32)
-        hipLaunchKernelGGL((k_lnprob<true>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region, c->pix(), (long long)W,
-                           th_d, lp_d, ch_d);
+        VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_lnprob<true, M>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region,
+                                                  c->pix(), (long long)W, th_d, lp_d, ch_d));
     else
-        hipLaunchKernelGGL((k_lnprob<false>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region, c->pix(), (long long)W,
-                           th_d, lp_d, ch_d);
+        VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_lnprob<false, M>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region,
+                                                  c->pix(), (long long)W, th_d, lp_d, ch_d));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(lnprob, lp_d, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (chi2) HIP_TRY(hipMemcpyAsync(chi2, ch_d, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -782,7 +823,8 @@ int vamp_model(vamp_ctx* c, int region, const double* theta1, double* tau_comp, 
     if (flux_model) HIP_TRY(hipMalloc(&fl_d, (size_t)R.P * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(th_d, theta1, R.D * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const unsigned grid = (unsigned)((R.P + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_model, dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region, c->pix(), th_d, tau_d, fl_d);
+    VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_model<M>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region, c->pix(),
+                                              th_d, tau_d, fl_d));
     HIP_TRY(hipGetLastError());
     if (tau_comp) HIP_TRY(hipMemcpyAsync(tau_comp, tau_d, (size_t)R.K * R.P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (flux_model) HIP_TRY(hipMemcpyAsync(flux_model, fl_d, (size_t)R.P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -790,6 +832,27 @@ int vamp_model(vamp_ctx* c, int region, const double* theta1, double* tau_comp, 
     (void)hipFree(th_d);
     if (tau_d) (void)hipFree(tau_d);
     if (fl_d) (void)hipFree(fl_d);
+    return VAMP_OK;
+}
+
+int vamp_line_records(vamp_ctx* c, int region, const double* theta1, double* rec, double* lnprior) {
+    if (!c || !theta1 || !rec || !lnprior) return fail(VAMP_ERR_ARG, "vamp_line_records: NULL argument");
+    if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_line_records: call vamp_set_regions first");
+    if (region < 0 || region >= c->n_regions) return fail(VAMP_ERR_ARG, "vamp_line_records: no such region");
+    HIP_TRY(hipSetDevice(c->device));
+    const RegionDev& R = c->regions_h[region];
+    double *th_d = nullptr, *rec_d = nullptr;
+    HIP_TRY(hipMalloc(&th_d, R.D * sizeof(double)));
+    HIP_TRY(hipMalloc(&rec_d, (5 * R.K + 1) * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(th_d, theta1, R.D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_line_records<M>), dim3(1), dim3(64), 0, c->stream, c->regions_d, region, th_d,
+                                              rec_d, rec_d + 5 * R.K));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rec, rec_d, 5 * R.K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(lnprior, rec_d + 5 * R.K, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(th_d);
+    (void)hipFree(rec_d);
     return VAMP_OK;
 }
 
@@ -860,12 +923,13 @@ int vamp_sampler_init(vamp_ctx* c, int64_t W, const double* theta0, uint64_t see
     for (int r = 0; r < c->n_regions; ++r) {
         const RegionDev& R = c->regions_h[r];
         const unsigned grid = (unsigned)((W + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+        double* nochi = nullptr;
         if (c->f32)
-            hipLaunchKernelGGL((k_lnprob<true>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r, c->pix(), (long long)W,
-                               c->X_d + R.theta_off, c->lnp_d + R.walker_off, nullptr);
+            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_lnprob<true, M>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r,
+                                                      c->pix(), (long long)W, c->X_d + R.theta_off, c->lnp_d + R.walker_off, nochi));
         else
-            hipLaunchKernelGGL((k_lnprob<false>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r, c->pix(), (long long)W,
-                               c->X_d + R.theta_off, c->lnp_d + R.walker_off, nullptr);
+            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_lnprob<false, M>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r,
+                                                      c->pix(), (long long)W, c->X_d + R.theta_off, c->lnp_d + R.walker_off, nochi));
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(c->stream));

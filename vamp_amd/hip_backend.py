@@ -132,6 +132,16 @@ class HipContext:
         _lib.check(self._lib.vamp_model(self._h, region, _dp(theta1), _dp(tau), _dp(flux)))
         return tau, flux
 
+    def line_records(self, theta1, region=0):
+        """(rec[K,5] = centroid, x-scale, y, tau scale, pole factor;  log-prior) as staged on device"""
+        theta1 = _f64(theta1).ravel()
+        if theta1.size != self.ndims[region]:
+            raise ValueError("theta1 has the wrong length")
+        rec = np.empty((self.n_comp[region], 5))
+        lp = C.c_double(0.0)
+        _lib.check(self._lib.vamp_line_records(self._h, region, _dp(theta1), _dp(rec), C.byref(lp)))
+        return rec, lp.value
+
     def wofz_re(self, x, y):
         x = _f64(x).ravel()
         y = _f64(y).ravel()
