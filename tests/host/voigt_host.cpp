@@ -7,7 +7,7 @@ extern "C" void voigt_H_host(int64_t n, const double* x, const double* y, double
     double dtab[vamp::DTAB_N];
     for (int64_t i = 0; i < n; ++i) {
         for (int k = 0; k < vamp::DTAB_N; ++k) dtab[k] = vamp::core_dtab_entry(k, y[i]);
-        out[i] = vamp::voigt_H(fabs(x[i]), y[i], dtab, vamp::core_pole_factor(y[i]));
+        out[i] = vamp::voigt_H(fabs(x[i]), y[i], dtab, vamp::core_pole_factor(y[i]), vamp::core_hy(y[i]));
     }
 }
 extern "C" void humlicek_w4_host(int64_t n, const float* x, const float* y, float* out) {

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvamp_hip.so")
+# VAMP_HIP_LIB: developer knob to A/B alternative builds of the same ABI (tools/tier_cost.py)
+LIB_PATH = os.environ.get("VAMP_HIP_LIB") or os.path.join(_HERE, "libvamp_hip.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

@@ -67,8 +67,9 @@ struct LineRec {           // per (walker, component), lives in LDS
     double c;              // centroid
     double s;              // Voigt: 2 sqrt(ln2)/G ; Gauss: 1/sigma
     double y;              // Voigt: L sqrt(ln2)/G
-    double amp;            // Voigt: A L sqrt(pi) sqrt(ln2) / G ; Gauss: A
+    double amp;            // Voigt: A y (tau_k = A y sqrt(pi) H: the evaluators return sqrt(pi) H) ; Gauss: A
     double pole;           // core_pole_factor(y)
+    double hy;             // core_hy(y)
 };
 
 struct WaveLds {
@@ -125,17 +126,19 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, in
         LineRec rec;
         rec.c = c;
         if constexpr (MODE == VAMP_GAUSS3) {
-            rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0;
+            rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0; rec.hy = 0.0;
         } else {
             rec.s = 2.0 * SQRT_LN2 / G;
             rec.y = Lw * SQRT_LN2 / G;
-            rec.amp = a * Lw * SQRT_PI * SQRT_LN2 / G;     // evaluation order of the oracle
+            rec.amp = a * rec.y;
             rec.pole = vamp::core_pole_factor(rec.y);
+            rec.hy = vamp::core_hy(rec.y);
         }
         L.line[lane] = rec;
         if (want_f32) {
             L.linef[lane][0] = (float)rec.c; L.linef[lane][1] = (float)rec.s;
-            L.linef[lane][2] = (float)rec.y; L.linef[lane][3] = (float)rec.amp;
+            L.linef[lane][2] = (float)rec.y;
+            L.linef[lane][3] = (float)(MODE == VAMP_GAUSS3 ? rec.amp : rec.amp * SQRT_PI);   // W4 returns H itself
         }
     }
     if (R.sample_sd && lane == KMAX) {      // one otherwise idle lane: sd ~ U(0,1), vpfits.py:39
@@ -153,31 +156,110 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, in
     return lp;
 }
 
+// sqrt(pi) H for the TPIX pixels a lane holds, with ONE branch for the whole wavefront.
+// Consecutive lanes hold consecutive pixels, so |z| is monotone along the wave on either side of
+// the line centre; the wave takes the deepest branch any of its pixels needs (a deeper J-fraction
+// is valid wherever a shallower one is).  Only waves that straddle |z|^2 = 64 diverge.
+#ifndef VAMP_TPIX
+#define VAMP_TPIX 2
+#endif
+constexpr int TPIX = VAMP_TPIX;      // pixels per lane per iteration
+
+template <int M>
+__device__ __forceinline__ void tile_jfrac(const double (&X)[TPIX], const double (&r2)[TPIX], double y, double (&H)[TPIX]) {
+#pragma unroll
+    for (int t = 0; t < TPIX; ++t) H[t] = vamp::voigt_jfrac<M>(X[t], y, r2[t]);
+}
+
+__device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab, const double (&X)[TPIX], double (&H)[TPIX]) {
+    const double y = ln.y;
+    const double y2 = y * y;
+    double r2[TPIX];
+    double lo;
+#pragma unroll
+    for (int t = 0; t < TPIX; ++t) {
+        r2[t] = fma(X[t], X[t], y2);
+        lo = t ? fmin(lo, r2[t]) : r2[0];
+    }
+    if (__any(lo < vamp::R2_M3)) {
+        if (__any(lo < vamp::R2_M4)) {
+            if (__any(lo < vamp::R2_CORE)) {
+#pragma unroll
+                for (int t = 0; t < TPIX; ++t) {
+                    if (r2[t] < vamp::R2_CORE) H[t] = vamp::voigt_core(X[t], y, dtab, ln.pole, ln.hy);
+                    else H[t] = vamp::voigt_jfrac<6>(X[t], y, r2[t]);
+                }
+                if (y < vamp::Y_TINY) {
+#pragma unroll
+                    for (int t = 0; t < TPIX; ++t)
+                        if (!(r2[t] < vamp::R2_CORE)) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
+                }
+                return;
+            }
+            tile_jfrac<6>(X, r2, y, H);
+        } else {
+            tile_jfrac<4>(X, r2, y, H);
+        }
+    } else if (__any(lo < vamp::R2_M2)) {
+        tile_jfrac<3>(X, r2, y, H);
+    } else if (__any(lo < vamp::R2_M1)) {
+        tile_jfrac<2>(X, r2, y, H);
+    } else {
+#pragma unroll
+        for (int t = 0; t < TPIX; ++t) H[t] = vamp::voigt_far(X[t], y, r2[t]);
+    }
+    if (y < vamp::Y_TINY) {       // wave-uniform (y belongs to the line): the fractions miss e^{-x^2}
+#pragma unroll
+        for (int t = 0; t < TPIX; ++t) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
+    }
+}
+
 // chi^2 sweep, fp64 pixel arithmetic.  Returns sum over the wave's pixels of ((f-m) w)^2.
+// A lane holds TPIX pixels (i, i+64, ...) per iteration: TPIX independent dependency chains and
+// one LDS read of the line record per TPIX evaluations.
 template <int MODE>
 __device__ __forceinline__ double sweep_f64(const RegionDev& R, const WaveLds& L, const double* __restrict__ x,
                                             const double* __restrict__ f, const double* __restrict__ wt, int lane) {
     double chi = 0.0;
     const int K = R.K, P = R.P;
     constexpr bool gauss = (MODE == VAMP_GAUSS3);
-    for (int i = lane; i < P; i += 64) {
-        const double xi = x[i];
-        double tau = 0.0;
+    for (int base = 0; base < P; base += 64 * TPIX) {
+        double xi[TPIX], tau[TPIX];
+        int idx[TPIX];
+#pragma unroll
+        for (int t = 0; t < TPIX; ++t) {
+            const int i = base + 64 * t + lane;
+            idx[t] = i < P ? i : P - 1;          // tail lanes recompute the last pixel and drop it
+            xi[t] = x[idx[t]];
+            tau[t] = 0.0;
+        }
         if constexpr (gauss) {
             for (int k = 0; k < K; ++k) {
-                const double u = (xi - L.line[k].c) * L.line[k].s;
-                tau += L.line[k].amp * exp(-0.5 * (u * u));
+                const double c = L.line[k].c, s = L.line[k].s, a = L.line[k].amp;
+#pragma unroll
+                for (int t = 0; t < TPIX; ++t) {
+                    const double u = (xi[t] - c) * s;
+                    tau[t] += a * exp(-0.5 * (u * u));
+                }
             }
         } else {
             for (int k = 0; k < K; ++k) {
-                const double X = fabs(xi - L.line[k].c) * L.line[k].s;
-                const double H = vamp::voigt_H(X, L.line[k].y, L.dtab[k], L.line[k].pole);
-                tau += L.line[k].amp * H;
+                const LineRec ln = L.line[k];
+                double X[TPIX], H[TPIX];
+#pragma unroll
+                for (int t = 0; t < TPIX; ++t) X[t] = fabs(xi[t] - ln.c) * ln.s;
+                tile_voigt(ln, L.dtab[k], X, H);
+#pragma unroll
+                for (int t = 0; t < TPIX; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
             }
         }
-        const double m = exp(-tau);
-        const double r = (f[i] - m) * wt[i];
-        chi = fma(r, r, chi);
+#pragma unroll
+        for (int t = 0; t < TPIX; ++t) {
+            const double m = exp(-tau[t]);
+            const double r = (f[idx[t]] - m) * wt[idx[t]];
+            const bool live = (base + 64 * t + lane) < P;
+            chi += live ? r * r : 0.0;
+        }
     }
     return wave_sum(chi);
 }
@@ -287,7 +369,7 @@ __global__ __launch_bounds__(BLOCK) void k_model(const RegionDev* __restrict__ r
             tk = L.line[k].amp * exp(-0.5 * (u * u));
         } else {
             const double X = fabs(xi - L.line[k].c) * L.line[k].s;
-            tk = L.line[k].amp * vamp::voigt_H(X, L.line[k].y, L.dtab[k], L.line[k].pole);
+            tk = L.line[k].amp * vamp::voigt_Hs(X, L.line[k].y, L.dtab[k], L.line[k].pole, L.line[k].hy);
         }
         if (tau_comp) tau_comp[(long long)k * R.P + i] = tk;
         tau += tk;
@@ -311,7 +393,7 @@ __global__ __launch_bounds__(64) void k_line_records(const RegionDev* __restrict
         rec[5 * lane + 0] = L.line[lane].c;
         rec[5 * lane + 1] = L.line[lane].s;
         rec[5 * lane + 2] = L.line[lane].y;
-        rec[5 * lane + 3] = L.line[lane].amp;
+        rec[5 * lane + 3] = (MODE == VAMP_GAUSS3) ? L.line[lane].amp : L.line[lane].amp * SQRT_PI;   // oracle's tau scale
         rec[5 * lane + 4] = L.line[lane].pole;
     }
     if (lane == 0) *lnprior = lp;
@@ -327,7 +409,7 @@ __global__ __launch_bounds__(BLOCK) void k_wofz(long long n, const double* __res
     } else {
         double dtab[vamp::DTAB_N];
         for (int k = 0; k < vamp::DTAB_N; ++k) dtab[k] = vamp::core_dtab_entry(k, y[i]);
-        out[i] = vamp::voigt_H(fabs(x[i]), y[i], dtab, vamp::core_pole_factor(y[i]));
+        out[i] = vamp::voigt_H(fabs(x[i]), y[i], dtab, vamp::core_pole_factor(y[i]), vamp::core_hy(y[i]));
     }
 }
 

@@ -38,9 +38,11 @@
 namespace vamp {
 
 constexpr double INV_SQRT_PI = 0.56418958354775628695;
+constexpr double SQRT_PI = 1.77245385090551602730;
 constexpr double PI = 3.14159265358979323846;
 constexpr int CORE_J = 13;           // half-width of the node window
-constexpr int DTAB_N = 32;           // entries of the per-line table 1/(u_n^2 + y^2), n = 0..28 used
+constexpr int DTAB_OFF = CORE_J;     // dtab[i] holds node n = i - DTAB_OFF  (n = -13 .. 30)
+constexpr int DTAB_N = 44;           // entries of the per-line table 1/(u_n^2 + y^2)
 constexpr double CORE_H = 0.5;
 constexpr double R2_CORE = 64.0;     // below: trapezoid
 constexpr double R2_M4 = 196.0;
@@ -49,6 +51,9 @@ constexpr double R2_M2 = 1.0e4;
 constexpr double R2_M1 = 1.0e8;
 constexpr double Y_POLE_MAX = 4.5;   // A(y) e^{-x^2} negligible beyond
 constexpr double Y_TINY = 1.0e-9;
+
+// All evaluators below return Hs = sqrt(pi) * H: the 1/sqrt(pi) of w(z) is folded into the
+// per-line tau scale (tau_k = A y Hs), one multiply less per pixel.
 
 VAMP_DEV double rcp_nr(double d) {
 #if defined(__HIPCC__)
@@ -71,82 +76,118 @@ VAMP_DEV double exp_neg_sq(double x) {
 }
 
 // Per-line constants of the near-axis rule, computed once per (walker, component).
-VAMP_DEV double core_dtab_entry(int n, double y) {
-    double u = (n + 0.5) * CORE_H;
+// Table entry i <-> node n = i - DTAB_OFF, u_n = (n + 1/2) h; d is even in u, so negative n need
+// no special casing and a pixel reads dtab[n0 + DTAB_OFF +- j] with compile-time offsets.
+VAMP_DEV double core_dtab_entry(int i, double y) {
+    double u = ((i - DTAB_OFF) + 0.5) * CORE_H;
     return 1.0 / (u * u + y * y);
 }
-VAMP_DEV double core_pole_factor(double y) {
+VAMP_DEV double core_pole_factor(double y) {      // sqrt(pi) * A(y)
     if (!(y < Y_POLE_MAX)) return 0.0;
     double t = exp(-2.0 * PI * y / CORE_H);
-    return 2.0 * exp(y * y - 2.0 * PI * y / CORE_H) / (1.0 + t);
+    return SQRT_PI * 2.0 * exp(y * y - 2.0 * PI * y / CORE_H) / (1.0 + t);
 }
+VAMP_DEV double core_hy(double y) { return (CORE_H * INV_SQRT_PI) * y; }
 
 // ---- J-fraction tiers -------------------------------------------------------------------
-// Re[ i z P(zeta) / Q(zeta) ] / sqrt(pi) = (ar*qi - ai*qr) / (sqrt(pi) |Q|^2),  a = z P
+// sqrt(pi) Re[ i z P(zeta) / (sqrt(pi) Q(zeta)) ] = (ar*qi - ai*qr) / |Q|^2,  a = z P
+// P, Q are monic with real coefficients; they are evaluated at the complex point zeta with the
+// real-coefficient (Goertzel/Knuth) recurrence, 2 FMAs per coefficient:
+//   u_N = 1, u_{N-1} = a_{N-1} + r, u_j = a_j + r u_{j+1} - s u_{j+2},  r = 2 Re zeta, s = |zeta|^2
+//   p(zeta) = zeta u_1 + (a_0 - s u_2)
 template <int M> struct JFrac;
 template <> struct JFrac<2> {
-    static constexpr int NP = 2, NQ = 3;
-    static constexpr double P[NP] = {-2.5, 1.0};
-    static constexpr double Q[NQ] = {0.75, -3.0, 1.0};
+    static constexpr int NP = 1, NQ = 2;
+    static constexpr double P[1] = {-2.5};
+    static constexpr double Q[2] = {0.75, -3.0};
 };
 template <> struct JFrac<3> {
-    static constexpr int NP = 3, NQ = 4;
-    static constexpr double P[NP] = {8.25, -7.0, 1.0};
-    static constexpr double Q[NQ] = {-1.875, 11.25, -7.5, 1.0};
+    static constexpr int NP = 2, NQ = 3;
+    static constexpr double P[2] = {8.25, -7.0};
+    static constexpr double Q[3] = {-1.875, 11.25, -7.5};
 };
 template <> struct JFrac<4> {
-    static constexpr int NP = 4, NQ = 5;
-    static constexpr double P[NP] = {-34.875, 46.25, -13.5, 1.0};
-    static constexpr double Q[NQ] = {6.5625, -52.5, 52.5, -14.0, 1.0};
+    static constexpr int NP = 3, NQ = 4;
+    static constexpr double P[3] = {-34.875, 46.25, -13.5};
+    static constexpr double Q[4] = {6.5625, -52.5, 52.5, -14.0};
 };
 template <> struct JFrac<6> {
-    static constexpr int NP = 6, NQ = 7;
-    static constexpr double P[NP] = {-1115.15625, 2605.3125, -1569.75, 355.5, -32.5, 1.0};
-    static constexpr double Q[NQ] = {162.421875, -1949.0625, 3248.4375, -1732.5, 371.25, -33.0, 1.0};
+    static constexpr int NP = 5, NQ = 6;
+    static constexpr double P[5] = {-1115.15625, 2605.3125, -1569.75, 355.5, -32.5};
+    static constexpr double Q[6] = {162.421875, -1949.0625, 3248.4375, -1732.5, 371.25, -33.0};
 };
 
-template <int M>
-VAMP_DEV double voigt_jfrac(double x, double y) {
-    using C = JFrac<M>;
-    const double zr = x * x - y * y;   // zeta
-    const double zi = 2.0 * x * y;
-    // monic complex Horner with real coefficients
-    double pr = zr + C::P[C::NP - 2], pi = zi;
+template <int N>
+VAMP_DEV void poly_monic(const double (&a)[N], double zr, double zi, double r, double s, double& re, double& im) {
+    if constexpr (N == 1) {
+        re = zr + a[0];
+        im = zi;
+    } else {
+        double u2 = 1.0, u1 = a[N - 1] + r;
 #pragma unroll
-    for (int j = C::NP - 3; j >= 0; --j) {
-        double t = fma(pr, zr, fma(-pi, zi, C::P[j]));
+        for (int j = N - 2; j >= 1; --j) {
+            const double t = fma(r, u1, fma(-s, u2, a[j]));
+            u2 = u1;
+            u1 = t;
+        }
+        re = fma(zr, u1, fma(-s, u2, a[0]));
+        im = zi * u1;
+    }
+}
+
+// plain complex Horner (4 FMAs per coefficient): used for the 6-level fraction, where the
+// 2-FMA recurrence loses a digit to cancellation near the real axis (3.5e-14 vs 4e-15)
+template <int N>
+VAMP_DEV void poly_monic_horner(const double (&a)[N], double zr, double zi, double& re, double& im) {
+    double pr = zr + a[N - 1], pi = zi;
+#pragma unroll
+    for (int j = N - 2; j >= 0; --j) {
+        const double t = fma(pr, zr, fma(-pi, zi, a[j]));
         pi = fma(pr, zi, pi * zr);
         pr = t;
     }
-    double qr = zr + C::Q[C::NQ - 2], qi = zi;
-#pragma unroll
-    for (int j = C::NQ - 3; j >= 0; --j) {
-        double t = fma(qr, zr, fma(-qi, zi, C::Q[j]));
-        qi = fma(qr, zi, qi * zr);
-        qr = t;
+    re = pr;
+    im = pi;
+}
+
+// r2 = x^2 + y^2 is passed in (the caller has it for the tier test)
+template <int M>
+VAMP_DEV double voigt_jfrac(double x, double y, double r2) {
+    using C = JFrac<M>;
+    const double zr = fma(x, x, -(y * y));   // zeta = z^2
+    const double zi = (x + x) * y;
+    double pr, pi, qr, qi;
+    if constexpr (M >= 6) {
+        poly_monic_horner<C::NP>(C::P, zr, zi, pr, pi);
+        poly_monic_horner<C::NQ>(C::Q, zr, zi, qr, qi);
+    } else {
+        const double r = zr + zr;
+        const double s = r2 * r2;            // |zeta|^2
+        poly_monic<C::NP>(C::P, zr, zi, r, s, pr, pi);
+        poly_monic<C::NQ>(C::Q, zr, zi, r, s, qr, qi);
     }
-    const double ar = x * pr - y * pi;
+    const double ar = fma(x, pr, -(y * pi));
     const double ai = fma(x, pi, y * pr);
-    const double num = ar * qi - ai * qr;
+    const double num = fma(ar, qi, -(ai * qr));
     const double den = fma(qr, qr, qi * qi);
-    return num * INV_SQRT_PI * rcp_nr(den);
+    return num * rcp_nr(den);
 }
 
 // |z|^2 >= 1e8: one level, K = 1/(zeta - 1/2); written so that huge |x| cannot overflow.
 VAMP_DEV double voigt_far(double x, double y, double r2) {
     const double inv = rcp_nr(r2);                 // r2 may be +inf -> 0
     const double eps = ((x * inv) * x - (y * inv) * y - 0.25 * inv) * inv;
-    return y * inv * INV_SQRT_PI * (1.0 + 0.5 * inv) * (1.0 + eps + eps * eps);
+    return y * inv * (1.0 + 0.5 * inv) * (1.0 + eps + eps * eps);
 }
 
 // ---- near-axis rule ---------------------------------------------------------------------
-// dtab[n] = 1/(u_n^2 + y^2) (n = 0 .. DTAB_N-1), pole = core_pole_factor(y); requires x < 8.
-VAMP_DEV double voigt_core(double x, double y, const double* dtab, double pole) {
+// dtab: core_dtab_entry table of the line, pole = core_pole_factor(y), hy = core_hy(y); x < 8.
+VAMP_DEV double voigt_core(double x, double y, const double* dtab, double pole, double hy) {
     const int n0 = (int)(x * 2.0);                       // floor(x/h)
     const double d = x - (n0 + 0.5) * CORE_H;            // |d| <= h/2
     const double d2 = d * d;
     // e^{-d^2}, e^{+d}, e^{-d} by short series (|d| <= 0.25)
-    double g0 = 2.7557319223985893e-06;                  // 1/9!  (u^9 term sign handled below)
+    double g0 = 2.7557319223985893e-06;                  // 1/9!
     g0 = fma(g0, -d2, 2.4801587301587302e-05);
     g0 = fma(g0, -d2, 1.9841269841269841e-04);
     g0 = fma(g0, -d2, 1.3888888888888889e-03);
@@ -179,43 +220,53 @@ VAMP_DEV double voigt_core(double x, double y, const double* dtab, double pole) 
         4.78511739212900875e-06, 1.12535174719259116e-07, 1.60522805518561165e-09,
         1.38879438649640209e-11, 7.28772409581969219e-14, 2.31952283024356963e-16,
         4.47773244171830150e-19};
-    double S = dtab[n0];
+    const double* p = dtab + n0 + DTAB_OFF;              // centre node; +-j are immediate offsets
+    double S = p[0];
     double qp = 1.0, qm = 1.0;
 #pragma unroll
     for (int j = 1; j <= CORE_J; ++j) {
         qp *= q;
         qm *= qi;
-        const int ip = n0 + j;
-        int im = n0 - j;
-        im = im >= 0 ? im : -im - 1;                     // d(u) is even: u_{-n-1} = -u_n
-        S = fma(CJ[j - 1], fma(qp, dtab[ip], qm * dtab[im]), S);
+        S = fma(CJ[j - 1], fma(qp, p[j], qm * p[-j]), S);
     }
-    double H = (CORE_H / PI) * y * (g0 * S);
+    double H = hy * (g0 * S);
     if (pole != 0.0) H = fma(pole * exp_neg_sq(x), cos(2.0 * x * y), H);
     return H;
 }
 
-// tier of a point: 0 = core, 1..5 = J-fraction with {6,4,3,2,1} levels
-VAMP_DEV int voigt_tier(double r2) {
-    return (r2 >= R2_CORE) + (r2 >= R2_M4) + (r2 >= R2_M3) + (r2 >= R2_M2) + (r2 >= R2_M1);
-}
-
-// Full evaluator. x >= 0 (caller passes |x|), y >= 0.  NaN in -> NaN out.
-VAMP_DEV double voigt_H(double x, double y, const double* dtab, double pole) {
+// Per-point evaluator (k_model, k_wofz, host tests).  x >= 0, y >= 0; returns sqrt(pi) H.
+VAMP_DEV double voigt_Hs(double x, double y, const double* dtab, double pole, double hy) {
     const double r2 = fma(x, x, y * y);
+#ifdef VAMP_FORCE_TIER   // timing-only builds (tools/tier_cost.py): every evaluation takes one branch
+    {
+        double xx = x < 7.9 ? x : 7.9;
+        if (VAMP_FORCE_TIER == 0) return voigt_core(xx, y, dtab, pole, hy);
+        if (VAMP_FORCE_TIER == 1) return voigt_jfrac<6>(x, y, r2);
+        if (VAMP_FORCE_TIER == 2) return voigt_jfrac<4>(x, y, r2);
+        if (VAMP_FORCE_TIER == 3) return voigt_jfrac<3>(x, y, r2);
+        if (VAMP_FORCE_TIER == 4) return voigt_jfrac<2>(x, y, r2);
+        if (VAMP_FORCE_TIER == 5) return voigt_far(x, y, r2);
+        return x * y;             // 6: no Voigt arithmetic at all (loop + staging overhead)
+    }
+#endif
     double H;
     if (r2 >= R2_M3) {
         if (r2 >= R2_M1) H = voigt_far(x, y, r2);
-        else if (r2 >= R2_M2) H = voigt_jfrac<2>(x, y);
-        else H = voigt_jfrac<3>(x, y);
+        else if (r2 >= R2_M2) H = voigt_jfrac<2>(x, y, r2);
+        else H = voigt_jfrac<3>(x, y, r2);
     } else if (r2 >= R2_CORE) {
-        if (r2 >= R2_M4) H = voigt_jfrac<4>(x, y);
-        else H = voigt_jfrac<6>(x, y);
+        if (r2 >= R2_M4) H = voigt_jfrac<4>(x, y, r2);
+        else H = voigt_jfrac<6>(x, y, r2);
     } else {
-        return voigt_core(x, y, dtab, pole);
+        return voigt_core(x, y, dtab, pole, hy);
     }
-    if (y < Y_TINY) H += exp_neg_sq(x);
+    if (y < Y_TINY) H += SQRT_PI * exp_neg_sq(x);
     return H;
+}
+
+// unscaled H = Re w(x + i y)
+VAMP_DEV double voigt_H(double x, double y, const double* dtab, double pole, double hy) {
+    return INV_SQRT_PI * voigt_Hs(x, y, dtab, pole, hy);
 }
 
 // ---- fp32: Humlicek W4 --------------------------------------------------------------------
