@@ -1,0 +1,443 @@
+"""``VPfit`` -- the reference's fit object (vamp_1.0/vpfits.py:33) on the MI355X hot path.
+
+Same constructor, method names, argument meaning and public attributes as the reference class, so
+``VPregion`` / ``VPspectrum`` / notebook code written against it runs unchanged; what differs is
+what sits underneath:
+
+  reference                                            here
+  -------------------------------------------------    ------------------------------------------
+  PyMC 2 model graph evaluated per proposal            HIP kernel: one wavefront per walker
+  (vpfits.py:239-260, 283-305, 334-341)                (csrc/vamp_hip.hip, k_lnprob / k_half_step)
+  one-at-a-time Metropolis, mc.MCMC.sample             affine-invariant stretch move, W walkers
+  (vpfits.py:379-393, 420-425)                         (vamp_sampler_*), counter-based RNG
+  mc.MAP.fit = scipy fmin on -logp                     scipy fmin (Nelder-Mead) on -logp, every
+  (vpfits.py:357-358, 419-426)                         evaluation a device call, started from the
+                                                       best walker
+  PyMC nodes (.value), mcmc.trace / stats, map.BIC     light stand-ins with the same attributes
+
+Sampler knobs keep their names: ``iterations`` = ensemble steps, ``burn``/``burnin`` = steps
+discarded, ``thin``/``thinning`` = keep every n-th step; each kept step contributes ``nwalkers``
+samples per parameter.  ``.value`` of every node is left at the MAP optimum after ``map.fit`` /
+``find_bic``, as PyMC leaves them (vpfits.py:426).
+
+Coordinates: the device works in region-centred units x = (nu - nu_mid)/dnu (dnu = mean pixel
+spacing), which keeps |x| small in fp64 and makes fp32 possible; every value handed back
+(traces, .value, sigma_max, ...) is in the caller's units (Hz).
+
+There is no CPU fallback: constructing the model needs libvamp_hip.so and a GPU.
+"""
+from __future__ import annotations
+
+import datetime
+
+import numpy as np
+
+from . import hip_backend as hb
+from .physics import *  # noqa: F401,F403  (the reference module does `from physics import *`)
+from .physics import Tau2flux
+
+FWHM_PER_SIGMA = 2.0 * np.sqrt(2.0 * np.log(2.0))
+
+
+class _Node:
+    """Stand-in for a PyMC node: callers only read ``.value`` (and ``__name__``)."""
+
+    def __init__(self, name, value=None):
+        self.__name__ = name
+        self.value = value
+
+    def __repr__(self):
+        return f"<node {self.__name__} = {self.value!r}>"
+
+
+class _Trace:
+    def __init__(self, samples):
+        self._s = samples
+
+    def __getitem__(self, idx):
+        return self._s[idx]
+
+    def __len__(self):
+        return len(self._s)
+
+    def gettrace(self, burn=0, thin=1):
+        return self._s[burn::thin]
+
+
+class _EnsembleMCMC:
+    """What callers use of ``mc.MCMC``: trace(name)[:], stats()[name]['standard deviation'],
+    DIC / BPIC (PyMC 2 definitions: deviance D = -2 log L; DIC = 2 mean(D) - D(mean theta),
+    BPIC = 3 mean(D) - 2 D(mean theta))."""
+
+    def __init__(self, fit):
+        self._fit = fit
+        self._traces = {}
+        self.DIC = None
+        self.BPIC = None
+        self.acceptance_fraction = None
+        self.walker_steps_per_second = None
+
+    def sample(self, iter, burn=0, thin=1, progress_bar=False, **_ignored):
+        self._fit._run_sampler(int(iter), int(burn), int(thin))
+
+    def trace(self, name):
+        return _Trace(self._traces[name])
+
+    def stats(self):
+        out = {}
+        for name, s in self._traces.items():
+            q = np.percentile(s, [2.5, 25, 50, 75, 97.5])
+            out[name] = {"n": s.size, "standard deviation": float(np.std(s)), "mean": float(np.mean(s)),
+                         "quantiles": {2.5: q[0], 25: q[1], 50: q[2], 75: q[3], 97.5: q[4]},
+                         "mc error": float(np.std(s) / np.sqrt(max(1, s.size)))}
+        return out
+
+
+class _MAP:
+    """What callers use of ``mc.MAP``: fit(iterlim, tol), BIC, AIC, lnL, logp_at_max (PyMC 2.3:
+    BIC = k ln(n_data) - 2 lnL, AIC = 2 k - 2 lnL, k = number of free scalars, lnL = log-likelihood
+    of the observed data at the optimum)."""
+
+    def __init__(self, fit):
+        self._fit = fit
+        self.BIC = self.AIC = self.lnL = self.logp_at_max = None
+        self.len = fit._ndim
+        self.data_len = fit._flux.size
+
+    def fit(self, iterlim=1000, tol=1e-3, **_ignored):
+        self._fit._run_map(int(iterlim), float(tol), self)
+
+
+class VPfit():
+
+    # ensemble size used by mcmc_fit / find_bic; may be changed per instance
+    nwalkers = 64
+
+    def __init__(self, noise=None, device=0, dtype=None, seed=None):
+        """noise=None reproduces the reference's free precision ``sd ~ U(0,1)`` (vpfits.py:39);
+        an array of per-pixel sigmas gives the known-noise chi^2 likelihood."""
+        self.noise = None if noise is None else np.asarray(noise, dtype=np.float64)
+        self.std_deviation = None if noise is None else 1.0 / self.noise ** 2
+        self.verbose = False
+        self.device = device
+        self.dtype = hb.F64 if dtype is None else dtype
+        self._seed = np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0] if seed is not None \
+            else np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0]
+        self._ctx = None
+
+    # ---- statics (vpfits.py:43-131), host numpy as in the reference -------------------------
+    @staticmethod
+    def GaussFunction(x, amplitude, centroid, sigma):
+        """Gaussian tau-profile (vpfits.py:43-54)"""
+        return amplitude * np.exp(-0.5 * ((x - centroid) / sigma) ** 2)
+
+    @staticmethod
+    def VoigtFunction(x, centroid, amplitude, L_fwhm, G_fwhm):
+        """Voigt tau-profile (vpfits.py:57-76), evaluated by the HIP Faddeeva code."""
+        x = np.asarray(x, dtype=np.float64)
+        order = np.argsort(x)
+        xs = x[order]
+        mid, dx = 0.5 * (xs[0] + xs[-1]), (xs[-1] - xs[0]) / max(1, xs.size - 1)
+        dx = dx if dx > 0 else 1.0
+        with hb.HipContext() as ctx:
+            ctx.set_regions((xs - mid) / dx, np.ones_like(xs), np.ones_like(xs), 1, mode=hb.MODE_VOIGT4)
+            tau, _ = ctx.model(np.array([amplitude, (centroid - mid) / dx, L_fwhm / dx, G_fwhm / dx]))
+        out = np.empty_like(x)
+        out[order] = tau[0]
+        return out
+
+    @staticmethod
+    def GaussianWidth(G_fwhm):
+        """sigma of the Gaussian part of a Voigt profile from its FWHM (vpfits.py:79-88)"""
+        return G_fwhm / (2. * np.sqrt(2. * np.log(2.)))
+
+    @staticmethod
+    def Chisquared(observed, expected, noise):
+        """chi^2 (vpfits.py:109-118)"""
+        return sum(((observed - expected) / noise) ** 2)
+
+    @staticmethod
+    def ReducedChisquared(observed, expected, noise, freedom):
+        """chi^2 / dof (vpfits.py:121-131)"""
+        return VPfit.Chisquared(observed, expected, noise) / freedom
+
+    # ---- model ------------------------------------------------------------------------------
+    def initialise_model(self, frequency, flux, n, local_minima=[], voigt=False):
+        """Build the posterior for ``n`` components (vpfits.py:310-349): upload the region once,
+        create the node stand-ins.  Prior bounds as in the reference: centroid ~ U(nu[0], nu[-1]),
+        sigma ~ U(0, sigma_max), L/G ~ U(0, fwhm_max), amplitude ~ x e^-x, sd ~ U(0,1)."""
+        frequency = np.asarray(frequency, dtype=np.float64)
+        flux = np.asarray(flux, dtype=np.float64)
+        self.sigma_max = (frequency[-1] - frequency[0]) / 2.
+        self._voigt = bool(voigt)
+        self._n = int(n)
+        self._freq, self._flux = frequency, flux
+        self._mid = 0.5 * (frequency[0] + frequency[-1])
+        self._dnu = (frequency[-1] - frequency[0]) / (frequency.size - 1)
+        self._x = (frequency - self._mid) / self._dnu
+        self._sample_sd = self.noise is None
+        if voigt:
+            if self.verbose:
+                print("Initialising Voigt profile components.")
+            self.fwhm_max = self.sigma_max * 2 * np.sqrt(2 * np.log(2.))
+        elif self.verbose:
+            print("Initialising Gaussian profile components.")
+        self._mode = hb.MODE_VOIGT4 if voigt else hb.MODE_GAUSS3
+        self._q = 4 if voigt else 3
+        self._ndim = self._q * self._n + (1 if self._sample_sd else 0)
+        noise = np.ones_like(flux) if self._sample_sd else self.noise
+        if self._ctx is None:
+            self._ctx = hb.HipContext(device=self.device, dtype=self.dtype)
+        self._ctx.set_regions(self._x, flux, noise, self._n, mode=self._mode, sample_sd=self._sample_sd)
+
+        # parameter names and unit scales (device units -> caller units)
+        names, keys, scale, shift = [], [], [], []
+        for k in range(self._n):
+            if voigt:
+                spec = (("xexp_%d", "amplitude", 1.0, 0.0), ("est_centroid_%d", "centroid", self._dnu, self._mid),
+                        ("est_L_%d", "L_fwhm", self._dnu, 0.0), ("est_G_%d", "G_fwhm", self._dnu, 0.0))
+            else:
+                spec = (("xexp_%d", "amplitude", 1.0, 0.0), ("est_centroid_%d", "centroid", self._dnu, self._mid),
+                        ("est_sigma_%d", "sigma", self._dnu, 0.0))
+            for nm, key, sc, sh in spec:
+                names.append(nm % k); keys.append((k, key)); scale.append(sc); shift.append(sh)
+        if self._sample_sd:
+            names.append("sd"); keys.append((None, "sd")); scale.append(1.0); shift.append(0.0)
+        self._names, self._keys = names, keys
+        self._scale, self._shift = np.array(scale), np.array(shift)
+
+        self.estimated_variables = {}
+        self.estimated_profiles = []
+        for k in range(self._n):
+            self.estimated_variables[k] = {}
+        for nm, (k, key) in zip(names, keys):
+            node = _Node(nm)
+            if k is None:
+                self._sd_node = node
+            else:
+                self.estimated_variables[k][key] = node
+        for k in range(self._n):
+            self.estimated_profiles.append(_Node("component_%d" % k))
+        self.total = _Node("profile")
+        self.profile = _Node("obs", flux)
+        self.model = [self.estimated_variables[k][key] for k in self.estimated_variables for key in self.estimated_variables[k]]
+
+        # initial point: amplitude 0.5 (vpfits.py:240), the rest drawn from their priors like PyMC
+        rng = np.random.default_rng(int(self._seed) & 0xFFFFFFFF)
+        self._theta_dev = self._draw_prior(rng, 1)[0]
+        self._theta_dev[0::self._q][:self._n] = 0.5
+        self._chain_dev = None
+        self._lnp_chain = None
+        self._set_values(self._theta_dev)
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _draw_prior(self, rng, W, local_minima=()):
+        x0, x1 = self._x[0], self._x[-1]
+        wmax = (x1 - x0) / 2. * (FWHM_PER_SIGMA if self._voigt else 1.0)
+        th = np.empty((W, self._ndim))
+        for k in range(self._n):
+            o = self._q * k
+            th[:, o] = rng.gamma(2.0, 1.0, W)                      # density x e^-x
+            th[:, o + 1] = rng.uniform(x0, x1, W)
+            for j in range(2, self._q):
+                th[:, o + j] = rng.uniform(0, wmax, W)
+        if self._sample_sd:
+            th[:, -1] = rng.uniform(0, 1, W)
+        return th
+
+    def _to_caller(self, theta_dev):
+        return theta_dev * self._scale + self._shift
+
+    def _set_values(self, theta_dev):
+        """Put one parameter vector on the nodes: .value of every variable, component and total."""
+        theta_dev = np.asarray(theta_dev, dtype=np.float64)
+        self._theta_dev = theta_dev.copy()
+        vals = self._to_caller(theta_dev)
+        for nm, (k, key), v in zip(self._names, self._keys, vals):
+            if k is None:
+                self._sd_node.value = float(v)
+            else:
+                self.estimated_variables[k][key].value = float(v)
+        tau, flux = self._ctx.model(theta_dev)
+        for k in range(self._n):
+            self.estimated_profiles[k].value = tau[k].copy()
+        self.total.value = flux
+
+    def _loglike(self, theta_dev):
+        """log-likelihood of the observed flux (device chi^2 / SSR, host epilogue)"""
+        lnp, s = self._ctx.lnprob(theta_dev, return_chi2=True)
+        th = np.atleast_2d(theta_dev)
+        if self._sample_sd:
+            t = 1.0 / th[:, -1] ** 2
+            ll = self._flux.size * 0.5 * np.log(t / (2 * np.pi)) - 0.5 * t * s
+        else:
+            ll = -0.5 * s - 0.5 * np.sum(np.log(2 * np.pi * self.noise ** 2))
+        return np.where(np.isfinite(lnp), ll, -np.inf)
+
+    # -- MAP ---------------------------------------------------------------------------------
+    def map_estimate(self, iterations=2000):
+        """Maximum a posteriori estimate (vpfits.py:352-358)."""
+        self.map = _MAP(self)
+        self.map.fit(iterlim=iterations, tol=1e-3)
+
+    def _run_map(self, iterlim, tol, mp):
+        from scipy.optimize import fmin
+        ctx = self._ctx
+
+        def neg(th):
+            v = ctx.lnprob(th)[0]
+            return -v if np.isfinite(v) else 1e300
+
+        start = self._theta_dev
+        if self._lnp_chain is not None:          # polish the best posterior sample of the ensemble
+            i = np.unravel_index(np.argmax(self._lnp_chain), self._lnp_chain.shape)
+            start = self._chain_dev[i[0], i[1]]
+        best = fmin(neg, start, xtol=tol, ftol=tol, maxiter=iterlim, maxfun=4 * iterlim, disp=False)
+        if neg(best) > neg(start):
+            best = start
+        self._set_values(best)
+        mp.logp_at_max = float(ctx.lnprob(best)[0])
+        mp.lnL = float(self._loglike(best)[0])
+        k, n = self._ndim, self._flux.size
+        mp.len, mp.data_len = k, n
+        mp.BIC = k * np.log(n) - 2.0 * mp.lnL
+        mp.AIC = 2.0 * k - 2.0 * mp.lnL
+
+    # -- MCMC --------------------------------------------------------------------------------
+    def mcmc_fit(self, iterations=15000, burnin=100, thinning=15, step_method=None):
+        """Sample the posterior (vpfits.py:361-395) with the stretch-move ensemble.  ``step_method``
+        is accepted for signature compatibility and ignored (there is one move)."""
+        try:
+            getattr(self, 'map')
+        except AttributeError:
+            print("\nWARNING: MAP estimate not provided. \nIt is recommended to compute this "
+                  "in advance of running the MCMC so as to start the sampling with good initial values.")
+        self.mcmc = _EnsembleMCMC(self)
+        starttime = datetime.datetime.now()
+        self.mcmc.sample(iter=iterations, burn=burnin, thin=thinning)
+        self.fit_time = str(datetime.datetime.now() - starttime)
+        print("\nTook:", self.fit_time, " to finish.")
+
+    def _run_sampler(self, iterations, burn, thin):
+        W = int(self.nwalkers)
+        W = max(W, 2 * self._ndim + 2)
+        W += W % 2
+        rng = np.random.default_rng((int(self._seed) >> 16) & 0xFFFFFFFF)
+        # walkers: a tight ball around the current point (the MAP, when map_estimate ran first),
+        # widened with prior draws so that a poor start cannot trap the whole ensemble
+        centre = self._theta_dev
+        span = np.abs(self._draw_prior(rng, W) - centre)
+        X0 = centre + 1e-2 * span * rng.standard_normal((W, self._ndim))
+        prior = self._draw_prior(rng, W)
+        lnp = self._ctx.lnprob(X0)
+        bad = ~np.isfinite(lnp)
+        X0[bad] = prior[bad]
+        X0[0] = centre
+        self._ctx.sampler_init(X0, seed=int(self._seed), a=2.0, split_block=hb.default_split_block(W))
+        if burn > 0:
+            self._ctx.run(burn, store_chain=False)
+        thin = max(1, thin)
+        keep = max(thin, iterations - burn)            # always keep at least one sample
+        res = self._ctx.run(keep, thin=thin)
+        chain, lnpc = res["chain"], res["lnprob"]          # [n_keep, W, D], [n_keep, W]
+        self._chain_dev, self._lnp_chain = chain, lnpc
+        flat = self._to_caller(chain.reshape(-1, self._ndim))
+        mc_ = self.mcmc
+        mc_._traces = {nm: flat[:, j].copy() for j, nm in enumerate(self._names)}
+        if self._voigt:      # the reference's callers ask for est_sigma_k in Voigt mode too (vpspectrum.py:400)
+            for k in range(self._n):
+                mc_._traces["est_sigma_%d" % k] = self.GaussianWidth(mc_._traces["est_G_%d" % k])
+        steps = burn + keep
+        mc_.acceptance_fraction = float(res["n_accept"].mean()) / max(1, steps)
+        mc_.walker_steps_per_second = W * keep / res["seconds"] if res["seconds"] > 0 else float("nan")
+        # information criteria from the chain (every kept sample scored on the device)
+        ll = self._loglike(chain.reshape(-1, self._ndim))
+        dev_mean = float(np.mean(-2.0 * ll[np.isfinite(ll)]))
+        mean_theta = chain.reshape(-1, self._ndim).mean(0)
+        dev_at_mean = float(-2.0 * self._loglike(mean_theta)[0])
+        mc_.DIC = 2 * dev_mean - dev_at_mean
+        mc_.BPIC = 3 * dev_mean - 2 * dev_at_mean
+        # leave the nodes at the best posterior sample (PyMC leaves them at the last sample)
+        i = np.unravel_index(np.argmax(lnpc), lnpc.shape)
+        self._set_values(chain[i[0], i[1]])
+
+    def find_bic(self, frequency_array, flux_array, n, noise_array, freedom, voigt=False,
+                 iterations=3000, thin=15, burn=300, thorough=False):
+        """Three independent {model, MCMC, MAP} repeats; collects map.BIC and the reduced chi^2 of
+        the MAP model (vpfits.py:398-429)."""
+        self.bic_array = []
+        self.red_chi_array = []
+        for i in range(3):
+            self._seed = (int(self._seed) * 6364136223846793005 + 1442695040888963407 + i) & (2 ** 64 - 1)
+            self.initialise_model(frequency_array, flux_array, n, voigt=voigt)
+            self.map = _MAP(self)
+            self.mcmc = _EnsembleMCMC(self)
+            if thorough:
+                self.map.fit(iterlim=iterations, tol=1e-3)
+                self.mcmc.sample(iter=iterations, burn=burn, thin=thin, progress_bar=False)
+                self.map.fit(iterlim=iterations, tol=1e-3)
+            self.mcmc.sample(iter=iterations, burn=burn, thin=thin, progress_bar=False)
+            self.map.fit(iterlim=iterations, tol=1e-3)
+            self.bic_array.append(self.map.BIC)
+            self.red_chi_array.append(self.ReducedChisquared(flux_array, self.total.value, noise_array, freedom))
+        return
+
+    def chain_covariance(self, n, voigt=False):
+        """Per-component 3x3 covariance of (amplitude, sigma, centroid) samples (vpfits.py:432-456)."""
+        cov = np.zeros((n, 3, 3))
+        for i in range(n):
+            amp_samples = self.mcmc.trace('xexp_' + str(i))[:]
+            if not voigt:
+                sigma_samples = self.mcmc.trace('est_sigma_' + str(i))[:]
+            else:
+                gfwhm_samples = self.mcmc.trace('est_G_' + str(i))[:]
+                sigma_samples = self.GaussianWidth(gfwhm_samples)
+            c_samples = self.mcmc.trace('est_centroid_' + str(i))[:]
+            cov[i] = np.cov(np.array((amp_samples, sigma_samples, c_samples)))
+        return cov
+
+    def plot(self, wavelength_array, flux_array, clouds=None, n=1, onesigmaerror=0.02,
+             start_pix=None, end_pix=None, filename=None):
+        """Residuals / components / total-fit figure (vpfits.py:134-199)."""
+        import matplotlib
+        if filename:
+            matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        if not start_pix:
+            start_pix = 0
+        if not end_pix:
+            end_pix = len(wavelength_array)
+        f, (ax1, ax2, ax3) = plt.subplots(3, sharex=True, sharey=False, figsize=(10, 10))
+        ax1.plot(wavelength_array, (flux_array - self.total.value) / onesigmaerror)
+        for lvl, ls in ((1, '-'), (-1, '-'), (3, '--'), (-3, '--')):
+            ax1.hlines(lvl, wavelength_array[0], wavelength_array[-1], color='red', linestyles=ls)
+        ax2.plot(wavelength_array, flux_array, color='black', linewidth=1.0)
+        if clouds is not None:
+            for c in range(len(clouds)):
+                ax2.plot(wavelength_array, Tau2flux(clouds.iloc[c]['tau'][start_pix:end_pix]), color="red",
+                         label="Actual" if c == 0 else None, lw=1.5)
+        for c in range(n):
+            ax2.plot(wavelength_array, Tau2flux(self.estimated_profiles[c].value), color="green",
+                     label="Fit" if c == 0 else None)
+        ax2.legend()
+        ax3.plot(wavelength_array, flux_array, label="Measured")
+        ax3.plot(wavelength_array, self.total.value, color='green', label="Fit", linewidth=2.0)
+        ax3.legend()
+        f.subplots_adjust(hspace=0)
+        if hasattr(self, 'fit_time'):
+            ax1.set_title("Fit time: " + self.fit_time)
+        ax1.set_ylabel("Residuals")
+        ax2.set_ylabel("Normalised Flux")
+        ax3.set_ylabel("Normalised Flux")
+        ax3.set_xlabel(r"$ \lambda (\AA)$")
+        if filename:
+            plt.savefig(filename)
+            plt.close(f)
+        else:
+            plt.show()
+
+    # copy.copy(fit) is used by VPregion (vpregion.py:65,72): share the device context
+    def __copy__(self):
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__.update(self.__dict__)
+        return new
