@@ -13,3 +13,6 @@ extern "C" void voigt_H_host(int64_t n, const double* x, const double* y, double
 extern "C" void humlicek_w4_host(int64_t n, const float* x, const float* y, float* out) {
     for (int64_t i = 0; i < n; ++i) out[i] = vamp::humlicek_w4_re(x[i], y[i]);
 }
+extern "C" void cos_small_host(int64_t n, const double* a, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = vamp::cos_small(a[i]);
+}

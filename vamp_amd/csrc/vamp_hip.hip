@@ -21,6 +21,7 @@
 // No MFMA (nothing here is a contraction), no atomics, no inter-workgroup communication.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -61,6 +62,7 @@ struct RegionDev {
     double lp_c, lp_w;     // -log(c_hi - c_lo), -log(w_max): uniform log-densities
     double l_fixed, line, x_origin, x_scale;   // NBZ3
     double norm_const;     // -1/2 sum log(2 pi sigma^2) or 0
+    double tile_span;      // 64 * TPIX * (largest pixel spacing of the region)
 };
 
 struct LineRec {           // per (walker, component), lives in LDS
@@ -70,6 +72,7 @@ struct LineRec {           // per (walker, component), lives in LDS
     double amp;            // Voigt: A y (tau_k = A y sqrt(pi) H: the evaluators return sqrt(pi) H) ; Gauss: A
     double pole;           // core_pole_factor(y)
     double hy;             // core_hy(y)
+    double wide;           // != 0: one tile of pixels spans more than 16 units of |z| (narrow line)
 };
 
 struct WaveLds {
@@ -126,13 +129,14 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, in
         LineRec rec;
         rec.c = c;
         if constexpr (MODE == VAMP_GAUSS3) {
-            rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0; rec.hy = 0.0;
+            rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0; rec.hy = 0.0; rec.wide = 0.0;
         } else {
             rec.s = 2.0 * SQRT_LN2 / G;
             rec.y = Lw * SQRT_LN2 / G;
             rec.amp = a * rec.y;
             rec.pole = vamp::core_pole_factor(rec.y);
             rec.hy = vamp::core_hy(rec.y);
+            rec.wide = (rec.s * R.tile_span <= 16.0) ? 0.0 : 1.0;    // NaN -> wide (safe path)
         }
         L.line[lane] = rec;
         if (want_f32) {
@@ -171,9 +175,20 @@ __device__ __forceinline__ void tile_jfrac(const double (&X)[TPIX], const double
     for (int t = 0; t < TPIX; ++t) H[t] = vamp::voigt_jfrac<M>(X[t], y, r2[t]);
 }
 
-__device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab, const double (&X)[TPIX], double (&H)[TPIX]) {
+__device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab, const double (&Xin)[TPIX], double (&H)[TPIX]) {
     const double y = ln.y;
     const double y2 = y * y;
+    const bool wide = ln.wide != 0.0;          // wave-uniform
+    double X[TPIX];
+#pragma unroll
+    for (int t = 0; t < TPIX; ++t) X[t] = Xin[t];
+    if (wide) {
+        // narrow line: |z| spans many units (possibly decades) inside one tile, and a lane promoted
+        // to a deep fraction would overflow |Q|^2 ~ |z|^(4m).  Clamp such lanes into the range of
+        // the fractions here and give them the closed far form below.  (NaN stays NaN.)
+#pragma unroll
+        for (int t = 0; t < TPIX; ++t) X[t] = (Xin[t] > vamp::X_FAR) ? vamp::X_FAR : Xin[t];
+    }
     double r2[TPIX];
     double lo;
 #pragma unroll
@@ -194,9 +209,13 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
                     for (int t = 0; t < TPIX; ++t)
                         if (!(r2[t] < vamp::R2_CORE)) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
                 }
-                return;
+            } else {
+                tile_jfrac<6>(X, r2, y, H);
+                if (y < vamp::Y_TINY) {
+#pragma unroll
+                    for (int t = 0; t < TPIX; ++t) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
+                }
             }
-            tile_jfrac<6>(X, r2, y, H);
         } else {
             tile_jfrac<4>(X, r2, y, H);
         }
@@ -206,11 +225,13 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
         tile_jfrac<2>(X, r2, y, H);
     } else {
 #pragma unroll
-        for (int t = 0; t < TPIX; ++t) H[t] = vamp::voigt_far(X[t], y, r2[t]);
+        for (int t = 0; t < TPIX; ++t) H[t] = vamp::voigt_far(Xin[t], y, fma(Xin[t], Xin[t], y2));
     }
-    if (y < vamp::Y_TINY) {       // wave-uniform (y belongs to the line): the fractions miss e^{-x^2}
+    // (for |z|^2 >= 196 the missing e^{-x^2} is < 1e-85: no tiny-y correction needed there)
+    if (wide) {
 #pragma unroll
-        for (int t = 0; t < TPIX; ++t) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
+        for (int t = 0; t < TPIX; ++t)
+            if (Xin[t] > vamp::X_FAR) H[t] = vamp::voigt_far(Xin[t], y, fma(Xin[t], Xin[t], y2));
     }
 }
 
@@ -825,6 +846,9 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
             nc *= -0.5;
         }
         d.norm_const = nc;
+        double dxmax = 0.0;
+        for (long long i = 1; i < P; ++i) dxmax = std::max(dxmax, std::fabs(xr[i] - xr[i - 1]));
+        d.tile_span = 64.0 * TPIX * dxmax;
         R[r] = d;
     }
     const long long N = pix_off[n_regions];
