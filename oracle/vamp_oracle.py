@@ -526,3 +526,57 @@ def region_from_spectrum(wavelength, flux, noise, start, end, **kw):
     f = flux[start:end][::-1]
     n = noise[start:end][::-1]
     return nu, f, n
+
+
+# --------------------------------------------------------------------------------------
+# Region detection, literal restatement of vpspectrum.py:67-175 (loops and full-length
+# np.convolve kernels as in the reference; O(N^2) -- used to pin the product's vectorised
+# detector and to generate the region fixture of the q1422 spectrum)
+# --------------------------------------------------------------------------------------
+def compute_detection_regions_ref(wavelength, flux, noise, min_region_width=2, N_sigma=4.0, std_min=2, std_max=11):
+    num_pixels = len(wavelength)
+    flux_ews = [0.] * num_pixels
+    noise_ews = [0.] * num_pixels
+    det_ratio = [-float('inf')] * num_pixels
+    for i in range(1, num_pixels - 1):                                   # :90-95
+        dec = 1.0 - flux[i]
+        if dec < noise[i]:
+            dec = 0.0
+        half = 0.5 * abs(wavelength[i - 1] - wavelength[i + 1])
+        flux_ews[i] = half * dec
+        noise_ews[i] = half * noise[i]
+    xarr = np.array([p - (num_pixels - 1) / 2.0 for p in range(num_pixels)])   # :102
+    for std in range(std_min, std_max):                                   # :105-117
+        gaussian = gauss_function(xarr, 1.0, 0.0, std)
+        flux_func = np.convolve(flux_ews, gaussian, 'same')
+        noise_func = np.convolve(np.square(noise_ews), np.square(gaussian), 'same')
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for i in range(1, num_pixels - 1):
+                nf = 1.0 / np.sqrt(noise_func[i])
+                if flux_func[i] * nf > det_ratio[i]:
+                    det_ratio[i] = flux_func[i] * nf
+    start = 0
+    endpoints = []
+    for i in range(num_pixels):                                           # :122-129
+        if start == 0 and det_ratio[i] > N_sigma and flux[i] < 1.0:
+            start = i
+        elif start != 0 and (det_ratio[i] < N_sigma or flux[i] > 1.0):
+            if (i - start) > min_region_width:
+                endpoints.append([start, i])
+            start = 0
+    pixels, waves = [], []
+    buffer = 3
+    for i in range(len(endpoints)):                                       # :157-173
+        s, e = endpoints[i]
+        if i < (len(endpoints) - 1) and e > endpoints[i + 1][0]:
+            e = endpoints[i + 1][1]
+        for j in range(s, e):
+            if (1.0 - flux[j]) > abs(noise[j]) * N_sigma:
+                if s >= buffer:
+                    s -= buffer
+                if e < num_pixels - buffer:
+                    e += buffer
+                waves.append([wavelength[s], wavelength[e]])
+                pixels.append([s, e])
+                break
+    return pixels, waves

@@ -319,3 +319,19 @@ if __name__ == "__main__":
     make_wofz_grid()
     make_lnprob_cases(simba)
     make_stretch(simba)
+    make_q1422()
+
+
+def make_q1422():
+    """vamp_1.0/data/q1422.cont (49 106 rows: wavelength, velocity, flux, noise), the spectrum of
+    BASELINE.json config 3, stored as exact integers: the file prints 3 / 6 decimals, and
+    int/10^k reproduces the parsed double exactly (one correctly rounded division)."""
+    a = np.loadtxt(os.path.join(REF, "data", "q1422.cont"))
+    wl = np.rint(a[:, 0] * 1000).astype(np.int32)
+    fl = np.rint(a[:, 2] * 1e6).astype(np.int32)
+    no = np.rint(a[:, 3] * 1e6).astype(np.int32)
+    assert np.array_equal(wl / 1000.0, a[:, 0]) and np.array_equal(fl / 1e6, a[:, 2]) and np.array_equal(no / 1e6, a[:, 3])
+    px, wv = vo.compute_detection_regions_ref(a[:, 0], a[:, 2], a[:, 3])       # oracle, full-length kernels
+    np.savez_compressed(os.path.join(HERE, "q1422_spectrum.npz"), wavelength_milli=wl, flux_micro=fl, noise_micro=no,
+                        region_pixels=np.array(px, dtype=np.int32))
+    print("q1422_spectrum.npz: %d pixels, %d regions" % (wl.size, len(px)))
