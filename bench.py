@@ -129,6 +129,21 @@ def cpu_baseline(wl, budget_s=12.0):
             "sample": f"C oracle (OpenMP, {cores} threads), first {Wc} walkers of the same workload x 1 step, {t:.1f} s"}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout at communicator creation; keep stdout for the one
+    JSON line by pointing fd 1 at stderr while the process group comes up and warms up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +156,8 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="do not record the chain inside the timed region")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the nccl process group and run the all-gather even with one rank (rehearsal)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,11 +171,15 @@ def main():
     import torch
     import vamp_amd
 
+    quiet = _StdoutToStderr()
+    quiet.__enter__()
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = make_workload(P=args.pixels, K=args.components, W=args.walkers, nbz=(args.param == "nbz3"))
     P, K, W, D = wl["P"], wl["K"], wl["W"], wl["D"]
@@ -170,8 +191,8 @@ def main():
     torch.cuda.set_device(local_rank)
     # walker state lives in torch tensors on torch's current stream (plumbing only): the RCCL
     # all-gather and the chain record are then ordered with the kernels without host syncs
-    ens = ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange="nccl" if world > 1 else "none",
-                          torch_device=torch.device("cuda", local_rank), torch_state=True)
+    ens = ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange="nccl" if dist is not None else "none",
+                          torch_device=torch.device("cuda", local_rank), torch_state=True, exchange_single_rank=args.force_dist)
     own = ens.own_end - ens.own_begin
 
     # chain storage (device resident): each rank records its own rows every step
@@ -191,6 +212,7 @@ def main():
 
     ens.step(args.warmup)
     sync_all()
+    quiet.__exit__()
     ctx.kernel_timing(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -215,6 +237,14 @@ def main():
         b_alg = algorithmic_bytes_per_walker_step(P, D, 8 if args.dtype == "f64" else 4)
         per_launch_units = own // 2                     # walker-steps of one half-step launch on this rank
         avg_ms = k_ms / max(1, k_n)
+        traffic = None
+        try:      # HBM bytes per launch from the committed PMC run of this same command (tools/pmc.sh)
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            c = pj["config"]
+            if (c["pixels"], c["components"], c["walkers"], c["ndim"], c["n_gpus"], c["dtype"]) == (P, K, W, D, world, args.dtype):
+                traffic = (2.0 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            pass
         achieved = per_launch_units * b_alg / (avg_ms * 1e-3) / 1e9 if k_n else None
         line = {
             "metric": "walker-steps/sec (log-posterior evals/sec)",
@@ -235,7 +265,9 @@ def main():
                        "pixels": P, "components": K, "walkers": W, "ndim": D, "parameterisation": args.param,
                        "chain_recorded": chain is not None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                         "traffic_unit": "bytes of HBM traffic per launch (PMC, separate passes)",
+                         "algorithmic_bytes_per_launch": per_launch_units * b_alg,
                          "kernel": "k_half_step", "avg_launch_ms": avg_ms, "launches": k_n,
                          "alg_bytes_per_walker_step": b_alg, "walker_steps_per_launch": per_launch_units},
             "faddeeva_gevals_per_s": value * P * K / 1e9,

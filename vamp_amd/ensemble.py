@@ -30,12 +30,14 @@ class ShardedEnsemble:
     """
 
     def __init__(self, backend, theta0, seed, a=2.0, split_block=None, dist=None, exchange="nccl", torch_device=None,
-                 torch_state=None):
+                 torch_state=None, exchange_single_rank=False):
         self.backend = backend
         self.dist = dist
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
-        self.exchange = exchange if self.world > 1 else "none"
+        # exchange_single_rank: keep the collective in the loop even for one rank (rehearses the
+        # RCCL call pattern on a one-GPU box; the gather is then a self-copy)
+        self.exchange = exchange if (self.world > 1 or (exchange_single_rank and dist is not None)) else "none"
         theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
         self.W, self.D = theta0.shape
         if split_block is None:
