@@ -47,7 +47,7 @@ def jfrac_polys(m):
 
 
 if __name__ == "__main__":
-    for m in (1, 2, 3, 4, 6):
+    for m in (1, 2, 3, 4, 6, 8):
         P, Q = jfrac_polys(m)
         print(f"// m = {m}: P (deg {len(P)-1}) low->high, Q (deg {len(Q)-1}) low->high")
         print("P%d = {" % m + ", ".join(repr(float(c)) for c in P) + "}")

@@ -72,7 +72,7 @@ struct LineRec {           // per (walker, component), lives in LDS
     double amp;            // Voigt: A y (tau_k = A y sqrt(pi) H: the evaluators return sqrt(pi) H) ; Gauss: A
     double pole;           // core_pole_factor(y)
     double hy;             // core_hy(y)
-    double wide;           // != 0: one tile of pixels spans more than 16 units of |z| (narrow line)
+    double xcap;           // +inf, or X_FAR when one tile of pixels spans > 16 units of |z| (narrow line)
 };
 
 struct WaveLds {
@@ -129,14 +129,17 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, in
         LineRec rec;
         rec.c = c;
         if constexpr (MODE == VAMP_GAUSS3) {
-            rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0; rec.hy = 0.0; rec.wide = 0.0;
+            rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0; rec.hy = 0.0; rec.xcap = __builtin_huge_val();
         } else {
             rec.s = 2.0 * SQRT_LN2 / G;
             rec.y = Lw * SQRT_LN2 / G;
             rec.amp = a * rec.y;
             rec.pole = vamp::core_pole_factor(rec.y);
             rec.hy = vamp::core_hy(rec.y);
-            rec.wide = (rec.s * R.tile_span <= 16.0) ? 0.0 : 1.0;    // NaN -> wide (safe path)
+            rec.xcap = (rec.s * R.tile_span <= 16.0) ? __builtin_huge_val() : vamp::X_FAR;   // NaN -> capped
+            // a degenerate width (G = 0 or non-finite scale) makes the reference's profile NaN, which
+            // its sampler rejects; reject here, before the sweep
+            if (!(rec.s < __builtin_huge_val()) || !(rec.y < __builtin_huge_val())) lp = NEG_INF;
         }
         L.line[lane] = rec;
         if (want_f32) {
@@ -171,24 +174,23 @@ constexpr int TPIX = VAMP_TPIX;      // pixels per lane per iteration
 
 template <int M>
 __device__ __forceinline__ void tile_jfrac(const double (&X)[TPIX], const double (&r2)[TPIX], double y, double (&H)[TPIX]) {
+    int t = 0;
 #pragma unroll
-    for (int t = 0; t < TPIX; ++t) H[t] = vamp::voigt_jfrac<M>(X[t], y, r2[t]);
+    for (; t + 1 < TPIX; t += 2) vamp::voigt_jfrac_x2<M>(X[t], X[t + 1], y, r2[t], r2[t + 1], H[t], H[t + 1]);
+    if (t < TPIX) H[t] = vamp::voigt_jfrac<M>(X[t], y, r2[t]);
 }
 
 __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab, const double (&Xin)[TPIX], double (&H)[TPIX]) {
     const double y = ln.y;
     const double y2 = y * y;
-    const bool wide = ln.wide != 0.0;          // wave-uniform
+    // narrow line: |z| spans many units (possibly decades) inside one tile, and a lane promoted to a
+    // deep fraction would overflow |Q|^2 ~ |z|^(4m).  Such lines carry xcap = X_FAR (else +inf):
+    // lanes beyond it are clamped into the range of the fractions here and get the closed far form
+    // below.  One v_min per evaluation; the patch is a wave-uniform branch.
+    const double xcap = ln.xcap;
     double X[TPIX];
 #pragma unroll
-    for (int t = 0; t < TPIX; ++t) X[t] = Xin[t];
-    if (wide) {
-        // narrow line: |z| spans many units (possibly decades) inside one tile, and a lane promoted
-        // to a deep fraction would overflow |Q|^2 ~ |z|^(4m).  Clamp such lanes into the range of
-        // the fractions here and give them the closed far form below.  (NaN stays NaN.)
-#pragma unroll
-        for (int t = 0; t < TPIX; ++t) X[t] = (Xin[t] > vamp::X_FAR) ? vamp::X_FAR : Xin[t];
-    }
+    for (int t = 0; t < TPIX; ++t) X[t] = fmin(Xin[t], xcap);
     double r2[TPIX];
     double lo;
 #pragma unroll
@@ -196,6 +198,23 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
         r2[t] = fma(X[t], X[t], y2);
         lo = t ? fmin(lo, r2[t]) : r2[0];
     }
+#ifdef VAMP_FORCE_TIER   // timing-only builds (tools/tier_cost.py): every tile takes one branch
+    {
+#pragma unroll
+        for (int t = 0; t < TPIX; ++t) {
+            const double xx = X[t] < 6.4 ? X[t] : 6.4;
+            if (VAMP_FORCE_TIER == 0) H[t] = vamp::voigt_core(xx, y, dtab, ln.pole, ln.hy);
+            else if (VAMP_FORCE_TIER == 1) H[t] = vamp::voigt_jfrac<6>(X[t], y, r2[t]);
+            else if (VAMP_FORCE_TIER == 2) H[t] = vamp::voigt_jfrac<4>(X[t], y, r2[t]);
+            else if (VAMP_FORCE_TIER == 3) H[t] = vamp::voigt_jfrac<3>(X[t], y, r2[t]);
+            else if (VAMP_FORCE_TIER == 4) H[t] = vamp::voigt_jfrac<2>(X[t], y, r2[t]);
+            else if (VAMP_FORCE_TIER == 5) H[t] = vamp::voigt_far(X[t], y, r2[t]);
+            else if (VAMP_FORCE_TIER == 7) H[t] = vamp::voigt_jfrac<8>(X[t], y, r2[t]);
+            else H[t] = X[t] * y;
+        }
+        return;
+    }
+#endif
     if (__any(lo < vamp::R2_M3)) {
         if (__any(lo < vamp::R2_M4)) {
             if (__any(lo < vamp::R2_CORE)) {
@@ -228,7 +247,7 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
         for (int t = 0; t < TPIX; ++t) H[t] = vamp::voigt_far(Xin[t], y, fma(Xin[t], Xin[t], y2));
     }
     // (for |z|^2 >= 196 the missing e^{-x^2} is < 1e-85: no tiny-y correction needed there)
-    if (wide) {
+    if (xcap < __builtin_huge_val()) {
 #pragma unroll
         for (int t = 0; t < TPIX; ++t)
             if (Xin[t] > vamp::X_FAR) H[t] = vamp::voigt_far(Xin[t], y, fma(Xin[t], Xin[t], y2));

@@ -151,6 +151,12 @@ template <> struct JFrac<6> {
     static constexpr double Q[6] = {162.421875, -1949.0625, 3248.4375, -1732.5, 371.25, -33.0};
 };
 
+template <> struct JFrac<8> {
+    static constexpr int NP = 7, NQ = 8;
+    static constexpr double P[7] = {-64803.8671875, 219904.453125, -203322.65625, 77869.6875, -14375.625, 1335.75, -59.5};
+    static constexpr double Q[8] = {7918.06640625, -126689.0625, 295607.8125, -236486.25, 84459.375, -15015.0, 1365.0, -60.0};
+};
+
 template <int N>
 VAMP_DEV void poly_monic(const double (&a)[N], double zr, double zi, double r, double s, double& re, double& im) {
     if constexpr (N == 1) {
@@ -184,12 +190,13 @@ VAMP_DEV void poly_monic_horner(const double (&a)[N], double zr, double zi, doub
     im = pi;
 }
 
-// r2 = x^2 + y^2 is passed in (the caller has it for the tier test)
+// numerator and denominator of sqrt(pi) Re w = num/den; r2 = x^2 + y^2 is passed in (the caller
+// has it for the tier test)
 template <int M>
-VAMP_DEV double voigt_jfrac(double x, double y, double r2) {
+VAMP_DEV void voigt_jfrac_nd(double x, double y, double r2, double& num, double& den) {
     using C = JFrac<M>;
     const double zr = fma(x, x, -(y * y));   // zeta = z^2
-    const double zi = (x + x) * y;
+    const double zi = x * (y + y);           // y + y is per line: hoisted out of the pixel loop
     double pr, pi, qr, qi;
     if constexpr (M >= 6) {
         poly_monic_horner<C::NP>(C::P, zr, zi, pr, pi);
@@ -202,9 +209,28 @@ VAMP_DEV double voigt_jfrac(double x, double y, double r2) {
     }
     const double ar = fma(x, pr, -(y * pi));
     const double ai = fma(x, pi, y * pr);
-    const double num = fma(ar, qi, -(ai * qr));
-    const double den = fma(qr, qr, qi * qi);
+    num = fma(ar, qi, -(ai * qr));
+    den = fma(qr, qr, qi * qi);
+}
+
+template <int M>
+VAMP_DEV double voigt_jfrac(double x, double y, double r2) {
+    double num, den;
+    voigt_jfrac_nd<M>(x, y, r2, num, den);
     return num * rcp_nr(den);
+}
+
+// Two evaluations share one reciprocal: 1/(d0 d1), then 1/d0 = r d1, 1/d1 = r d0 (one v_rcp_f64
+// and one Newton pair instead of two; den <= 1e96 for every lane a fraction may see, so the
+// product stays far inside the fp64 range).
+template <int M>
+VAMP_DEV void voigt_jfrac_x2(double x0, double x1, double y, double r20, double r21, double& h0, double& h1) {
+    double n0, d0, n1, d1;
+    voigt_jfrac_nd<M>(x0, y, r20, n0, d0);
+    voigt_jfrac_nd<M>(x1, y, r21, n1, d1);
+    const double r = rcp_nr(d0 * d1);
+    h0 = n0 * (r * d1);
+    h1 = n1 * (r * d0);
 }
 
 // |z|^2 >= 1e8: one level, K = 1/(zeta - 1/2); written so that huge |x| cannot overflow.
