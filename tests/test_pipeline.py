@@ -162,3 +162,34 @@ def test_fit_spectrum_end_to_end_and_cli(tmp_path):
         for s, e in g["CII1036_region_pixels"]:
             mask[s:e] = False
         assert np.all(fm["total"][mask] == 1.0)
+
+
+@pytest.mark.gpu
+def test_config3_all_regions_batched():
+    """BASELINE.json config 3 at a reduced walker count: all 421 q1422 regions (ragged CSR batch,
+    1..8 Voigt components) in one launch per half-step; the sampler state stays self-consistent and
+    a sample of regions follows the oracle."""
+    import vamp_amd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_c3 import build_regions, start_walkers
+    xs, fs, ns, ks = build_regions()
+    assert len(xs) == 421 and max(ks) == 8 and min(ks) == 1
+    rng = np.random.default_rng(1422)
+    W = 32
+    theta0 = [start_walkers(rng, x, k, W) for x, k in zip(xs, ks)]
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(xs, fs, ns, ks, mode=vamp_amd.MODE_VOIGT4)
+        ctx.sampler_init(theta0, seed=99, split_block=W)
+        ctx.run(4, store_chain=False)
+        X, lnp, nacc, step = ctx.get_state()
+        assert step == 4
+        for r in (0, 7, 100, 333, 420):
+            fresh = ctx.lnprob(X[r], region=r)
+            assert np.array_equal(np.isfinite(fresh), np.isfinite(lnp[r]))
+            fin = np.isfinite(fresh)
+            assert np.allclose(fresh[fin], lnp[r][fin], rtol=1e-12, atol=1e-9)
+            reg = vo.Region(x=xs[r], flux=fs[r], noise=ns[r], n_comp=ks[r], mode=vo.MODE_VOIGT4)
+            fn = lambda q, reg=reg: vo.log_prob_batch_fast(reg, q)
+            chain, lchain, na = vo.run_sampler(fn, theta0[r], fn(theta0[r]), 4, seed=99, block=W, region=r, walker_off=r * W)
+            assert np.allclose(X[r], chain[-1], rtol=1e-9, atol=1e-11), r
+            assert np.array_equal(nacc[r], na), r

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 2: H I Ly-alpha region [672,716] of simba_H1215 (44 px), 4 Voigt components,
+4096 walkers, fp64, one GPU.   python tools/bench_c2.py [--steps 2000] [--walkers 4096] [--comp 4]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--walkers", type=int, default=4096)
+ap.add_argument("--steps", type=int, default=2000)
+ap.add_argument("--comp", type=int, default=4)
+ap.add_argument("--dtype", default="f64")
+a = ap.parse_args()
+import vamp_amd
+from vamp_amd.physics import Wave2freq
+g = np.load(os.path.join(ROOT, "tests", "golden", "simba_spectra.npz"))
+s, e = g["H1215_region_pixels"][0]
+nu = np.flip(Wave2freq(g["H1215_wavelength"][s:e]), 0)
+flux, noise = np.flip(g["H1215_flux"][s:e], 0), np.flip(g["H1215_noise"][s:e], 0)
+x = (nu - 0.5 * (nu[0] + nu[-1])) / ((nu[-1] - nu[0]) / (nu.size - 1))
+rng = np.random.default_rng(2)
+K, W = a.comp, a.walkers
+th = np.empty((W, 4 * K))
+for k in range(K):
+    th[:, 4 * k] = rng.gamma(2.0, 1.0, W)
+    th[:, 4 * k + 1] = rng.uniform(x[0], x[-1], W)
+    th[:, 4 * k + 2] = rng.uniform(0.5, 8, W)
+    th[:, 4 * k + 3] = rng.uniform(2, 15, W)
+ctx = vamp_amd.HipContext(device=0, dtype=vamp_amd.F64 if a.dtype == "f64" else vamp_amd.F32)
+ctx.set_regions(x, flux, noise, K, mode=vamp_amd.MODE_VOIGT4)
+ctx.sampler_init(th, seed=5)
+ctx.run(50, store_chain=False)
+ctx.kernel_timing(True)
+t0 = time.perf_counter()
+res = ctx.run(a.steps, thin=10)
+dt = time.perf_counter() - t0
+ms, n = ctx.kernel_timing(False)
+print(json.dumps({"config": f"simba H I region, P={x.size}, K={K}, W={W}, {a.dtype}", "walker_steps_per_s": W * a.steps / dt,
+                  "us_per_half_step_wall": dt / a.steps / 2 * 1e6, "us_per_half_step_kernel": ms / max(1, n) * 1e3,
+                  "faddeeva_gevals_per_s": W * a.steps * x.size * K / dt / 1e9,
+                  "acceptance_fraction": float(res["n_accept"].mean()) / (a.steps + 50)}))
