@@ -23,10 +23,13 @@ def golden():
     return load_golden
 
 
-@pytest.fixture(scope="session")
-def hip_ctx():
-    """fp64 / accurate-wofz context on device 0 (GPU tests only)."""
+@pytest.fixture(scope="session", params=[0, 64, 16], ids=["pack-auto", "pack-64", "pack-16"])
+def hip_ctx(request):
+    """fp64 / accurate-wofz context on device 0 (GPU tests only), once per walker packing:
+    automatic, one walker per wavefront, four walkers per wavefront."""
     import vamp_amd
     ctx = vamp_amd.HipContext(device=0)
+    ctx.set_packing(request.param)
+    ctx.packing_request = request.param
     yield ctx
     ctx.close()

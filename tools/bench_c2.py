@@ -17,6 +17,7 @@ ap.add_argument("--walkers", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--comp", type=int, default=4)
 ap.add_argument("--dtype", default="f64")
+ap.add_argument("--packing", type=int, default=0)
 a = ap.parse_args()
 import vamp_amd
 from vamp_amd.physics import Wave2freq
@@ -34,6 +35,7 @@ for k in range(K):
     th[:, 4 * k + 2] = rng.uniform(0.5, 8, W)
     th[:, 4 * k + 3] = rng.uniform(2, 15, W)
 ctx = vamp_amd.HipContext(device=0, dtype=vamp_amd.F64 if a.dtype == "f64" else vamp_amd.F32)
+ctx.set_packing(a.packing)
 ctx.set_regions(x, flux, noise, K, mode=vamp_amd.MODE_VOIGT4)
 ctx.sampler_init(th, seed=5)
 ctx.run(50, store_chain=False)
@@ -45,4 +47,4 @@ ms, n = ctx.kernel_timing(False)
 print(json.dumps({"config": f"simba H I region, P={x.size}, K={K}, W={W}, {a.dtype}", "walker_steps_per_s": W * a.steps / dt,
                   "us_per_half_step_wall": dt / a.steps / 2 * 1e6, "us_per_half_step_kernel": ms / max(1, n) * 1e3,
                   "faddeeva_gevals_per_s": W * a.steps * x.size * K / dt / 1e9,
-                  "acceptance_fraction": float(res["n_accept"].mean()) / (a.steps + 50)}))
+                  "acceptance_fraction": float(res["n_accept"].mean()) / (a.steps + 50), "packing": a.packing}))

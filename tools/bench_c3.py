@@ -53,11 +53,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--packing", type=int, default=0, help="lanes per walker: 0 auto, 16, 64")
     a = ap.parse_args()
     import vamp_amd
     xs, fs, ns, ks = build_regions()
     rng = np.random.default_rng(1422)
     ctx = vamp_amd.HipContext(device=0, dtype=vamp_amd.F64 if a.dtype == "f64" else vamp_amd.F32)
+    ctx.set_packing(a.packing)
     ctx.set_regions(xs, fs, ns, ks, mode=vamp_amd.MODE_VOIGT4)
     theta0 = [start_walkers(rng, x, k, a.walkers) for x, k in zip(xs, ks)]
     ctx.sampler_init(theta0, seed=1422, split_block=vamp_amd.default_split_block(a.walkers))
@@ -79,7 +81,7 @@ def main():
                       "region_walker_steps_per_s": R * a.walkers * a.steps / dt, "ms_per_step": dt / a.steps * 1e3,
                       "avg_launch_ms": ms / max(1, n), "faddeeva_gevals_per_s": evals * a.steps / dt / 1e9,
                       "algorithmic_GBps": b_alg * a.steps / dt / 1e9, "hbm_frac": b_alg * a.steps / dt / 8e12,
-                      "acceptance_fraction": float(acc)}))
+                      "acceptance_fraction": float(acc), "packing": a.packing}))
 
 
 if __name__ == "__main__":

@@ -40,6 +40,7 @@ constexpr int KMAX = VAMP_MAX_COMPONENTS;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
 constexpr int DMAX = 4 * KMAX + 1;
+constexpr long long PACK_MIN_WALKERS = 16384;   // automatic packing: walkers per launch needed to pay off
 
 constexpr double C_LIGHT = 2.98e8;     // physics.py:3 (the reference's value)
 constexpr double SIGMA0 = 0.0263;      // physics.py:4
@@ -75,19 +76,33 @@ struct LineRec {           // per (walker, component), lives in LDS
     double xcap;           // +inf, or X_FAR when one tile of pixels spans > 16 units of |z| (narrow line)
 };
 
-struct WaveLds {
-    double theta[DMAX + 3];
-    LineRec line[KMAX];
-    double dtab[KMAX][vamp::DTAB_N];
-    float linef[KMAX][4];  // fp32 path: c, s, y, amp
+// Packing of walkers onto wavefronts.  LPW lanes serve one walker (SUBS = 64/LPW walkers share a
+// wave); KCAP bounds the lines per walker and so the LDS footprint.  <64,16> is the headline shape
+// (thousands of pixels per region); <16,8> serves the 9..478-pixel regions of real spectra, where
+// one walker cannot fill a wave and the per-walker fixed work (staging, draws, reduction) dominates.
+template <int LPW_, int KCAP_>
+struct Pack {
+    static constexpr int LPW = LPW_, KCAP = KCAP_, SUBS = 64 / LPW_;
 };
+using PackWide = Pack<64, KMAX>;
+using PackSmall = Pack<16, 8>;
+
+template <int KCAP>
+struct WalkerLds {
+    double theta[4 * KCAP + 4];
+    LineRec line[KCAP];
+    double dtab[KCAP][vamp::DTAB_N];
+    float linef[KCAP][4];  // fp32 path: c, s, y, amp
+};
+using WaveLds = WalkerLds<KMAX>;
 
 // ---------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
+template <int LPW = 64>
+__device__ __forceinline__ double wave_sum(double v) {      // sum over the LPW lanes of one walker
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int off = LPW / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
@@ -103,8 +118,9 @@ __device__ __forceinline__ double uniform_logp(double v, double lo, double hi, d
 // Turn theta (in LDS) into line records + prior.  Returns log-prior on every lane.
 // MODE is a compile-time parameter: one specialised kernel per parameterisation, no mode
 // branches in the staging code or in the pixel loop.
-template <int MODE>
-__device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, int lane, bool want_f32) {
+template <int MODE, class PK = PackWide>
+__device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::KCAP>& L, int lane, bool want_f32) {
+    // `lane` is the lane index inside the walker's group (0 .. LPW-1)
     double lp = 0.0;
     const int K = R.K;
     constexpr int Q = (MODE == VAMP_VOIGT4) ? 4 : 3;
@@ -136,7 +152,9 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, in
             rec.amp = a * rec.y;
             rec.pole = vamp::core_pole_factor(rec.y);
             rec.hy = vamp::core_hy(rec.y);
-            rec.xcap = (rec.s * R.tile_span <= 16.0) ? __builtin_huge_val() : vamp::X_FAR;   // NaN -> capped
+            // packed waves: another walker of the wave may force a deep fraction on this one, so every
+            // line is capped there
+            rec.xcap = (PK::SUBS == 1 && rec.s * R.tile_span <= 16.0) ? __builtin_huge_val() : vamp::X_FAR;   // NaN -> capped
             // a degenerate width (G = 0 or non-finite scale) makes the reference's profile NaN, which
             // its sampler rejects; reject here, before the sweep
             if (!(rec.s < __builtin_huge_val()) || !(rec.y < __builtin_huge_val())) lp = NEG_INF;
@@ -148,13 +166,13 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WaveLds& L, in
             L.linef[lane][3] = (float)(MODE == VAMP_GAUSS3 ? rec.amp : rec.amp * SQRT_PI);   // W4 returns H itself
         }
     }
-    if (R.sample_sd && lane == KMAX) {      // one otherwise idle lane: sd ~ U(0,1), vpfits.py:39
+    if (R.sample_sd && lane == PK::KCAP) {      // one otherwise idle lane: sd ~ U(0,1), vpfits.py:39
         lp = uniform_logp(L.theta[R.D - 1], 0.0, 1.0, 0.0);
     }
-    lp = wave_sum(lp);
+    lp = wave_sum<PK::LPW>(lp);
     __builtin_amdgcn_wave_barrier();
     if (MODE != VAMP_GAUSS3 && !want_f32) {
-        for (int e = lane; e < K * vamp::DTAB_N; e += 64) {
+        for (int e = lane; e < K * vamp::DTAB_N; e += PK::LPW) {
             const int k = e / vamp::DTAB_N, n = e % vamp::DTAB_N;
             L.dtab[k][n] = vamp::core_dtab_entry(n, L.line[k].y);
         }
@@ -257,18 +275,19 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
 // chi^2 sweep, fp64 pixel arithmetic.  Returns sum over the wave's pixels of ((f-m) w)^2.
 // A lane holds TPIX pixels (i, i+64, ...) per iteration: TPIX independent dependency chains and
 // one LDS read of the line record per TPIX evaluations.
-template <int MODE>
-__device__ __forceinline__ double sweep_f64(const RegionDev& R, const WaveLds& L, const double* __restrict__ x,
+template <int MODE, class PK = PackWide>
+__device__ __forceinline__ double sweep_f64(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x,
                                             const double* __restrict__ f, const double* __restrict__ wt, int lane) {
     double chi = 0.0;
     const int K = R.K, P = R.P;
     constexpr bool gauss = (MODE == VAMP_GAUSS3);
-    for (int base = 0; base < P; base += 64 * TPIX) {
+    constexpr int LPW = PK::LPW;
+    for (int base = 0; base < P; base += LPW * TPIX) {
         double xi[TPIX], tau[TPIX];
         int idx[TPIX];
 #pragma unroll
         for (int t = 0; t < TPIX; ++t) {
-            const int i = base + 64 * t + lane;
+            const int i = base + LPW * t + lane;
             idx[t] = i < P ? i : P - 1;          // tail lanes recompute the last pixel and drop it
             xi[t] = x[idx[t]];
             tau[t] = 0.0;
@@ -297,21 +316,21 @@ __device__ __forceinline__ double sweep_f64(const RegionDev& R, const WaveLds& L
         for (int t = 0; t < TPIX; ++t) {
             const double m = exp(-tau[t]);
             const double r = (f[idx[t]] - m) * wt[idx[t]];
-            const bool live = (base + 64 * t + lane) < P;
+            const bool live = (base + LPW * t + lane) < P;
             chi += live ? r * r : 0.0;
         }
     }
-    return wave_sum(chi);
+    return wave_sum<LPW>(chi);
 }
 
 // fp32 pixel arithmetic (Humlicek W4), chi^2 accumulated in fp64 (SURVEY section 7 hard parts).
-template <int MODE>
-__device__ __forceinline__ double sweep_f32(const RegionDev& R, const WaveLds& L, const float* __restrict__ x,
+template <int MODE, class PK = PackWide>
+__device__ __forceinline__ double sweep_f32(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const float* __restrict__ x,
                                             const float* __restrict__ f, const float* __restrict__ wt, int lane) {
     double chi = 0.0;
     const int K = R.K, P = R.P;
     constexpr bool gauss = (MODE == VAMP_GAUSS3);
-    for (int i = lane; i < P; i += 64) {
+    for (int i = lane; i < P; i += PK::LPW) {
         const float xi = x[i];
         float tau = 0.0f;
         if constexpr (gauss) {
@@ -329,11 +348,12 @@ __device__ __forceinline__ double sweep_f32(const RegionDev& R, const WaveLds& L
         const float r = (f[i] - m) * wt[i];
         chi += (double)r * (double)r;
     }
-    return wave_sum(chi);
+    return wave_sum<PK::LPW>(chi);
 }
 
 // log-likelihood from the reduced sum (both forms of SURVEY Appendix A)
-__device__ __forceinline__ double loglike_from_sum(const RegionDev& R, const WaveLds& L, double ssum) {
+template <class LDS>
+__device__ __forceinline__ double loglike_from_sum(const RegionDev& R, const LDS& L, double ssum) {
     if (R.sample_sd) {
         const double sd = L.theta[R.D - 1];
         const double t = 1.0 / (sd * sd);
@@ -347,16 +367,20 @@ struct PixPtrs {
     const float* xf; const float* ff; const float* wtf;       // fp32 copies (may be null)
 };
 
-template <bool F32, int MODE>
-__device__ __forceinline__ double wave_lnprob(const RegionDev& R, WaveLds& L, const PixPtrs& px, int lane, double* chi_out) {
-    const double lp = stage_lines<MODE>(R, L, lane, F32);
+// log-posterior of the walker whose parameters sit in L.theta; `lane` = lane inside the walker's
+// group.  Groups of one wave may leave early independently: everything below communicates only
+// inside a group (xor shuffles with offsets < LPW) or through __any, which ignores inactive lanes.
+template <bool F32, int MODE, class PK = PackWide>
+__device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::KCAP>& L, const PixPtrs& px, int lane,
+                                              double* chi_out) {
+    const double lp = stage_lines<MODE, PK>(R, L, lane, F32);
     if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
         if (chi_out) *chi_out = __builtin_nan("");
         return NEG_INF;
     }
     double ssum;
-    if constexpr (F32) ssum = sweep_f32<MODE>(R, L, px.xf + R.pix_off, px.ff + R.pix_off, px.wtf + R.pix_off, lane);
-    else ssum = sweep_f64<MODE>(R, L, px.x + R.pix_off, px.f + R.pix_off, px.wt + R.pix_off, lane);
+    if constexpr (F32) ssum = sweep_f32<MODE, PK>(R, L, px.xf + R.pix_off, px.ff + R.pix_off, px.wtf + R.pix_off, lane);
+    else ssum = sweep_f64<MODE, PK>(R, L, px.x + R.pix_off, px.f + R.pix_off, px.wt + R.pix_off, lane);
     if (chi_out) *chi_out = ssum;
     double v = lp + loglike_from_sum(R, L, ssum);
     if (v != v) v = NEG_INF;                 // NaN -> -inf (emcee convention)
@@ -366,21 +390,22 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WaveLds& L, co
 // ---------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------
-template <bool F32, int MODE>
+template <bool F32, int MODE, class PK>
 __global__ __launch_bounds__(BLOCK) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
                                                   long long W, const double* __restrict__ theta,
                                                   double* __restrict__ lnprob, double* __restrict__ chi2) {
-    __shared__ WaveLds lds[WAVES_PER_BLOCK];
+    __shared__ WalkerLds<PK::KCAP> lds[WAVES_PER_BLOCK * PK::SUBS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long w = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int sub = lane / PK::LPW, l = lane % PK::LPW;
+    const long long w = ((long long)blockIdx.x * WAVES_PER_BLOCK + wave) * PK::SUBS + sub;
     if (w >= W) return;
     const RegionDev R = regions[region];
-    WaveLds& L = lds[wave];
-    for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[w * R.D + d];
+    WalkerLds<PK::KCAP>& L = lds[wave * PK::SUBS + sub];
+    for (int d = l; d < R.D; d += PK::LPW) L.theta[d] = theta[w * R.D + d];
     __builtin_amdgcn_wave_barrier();
     double chi;
-    const double v = wave_lnprob<F32, MODE>(R, L, px, lane, &chi);
-    if (lane == 0) {
+    const double v = wave_lnprob<F32, MODE, PK>(R, L, px, l, &chi);
+    if (l == 0) {
         lnprob[w] = v;
         if (chi2) chi2[w] = chi;
     }
@@ -511,15 +536,17 @@ struct SamplerDev {
 
 // One half-step of the stretch move, one wavefront per active walker.
 //   EXT = draws supplied by the host (deterministic-parity hook); else Philox in-kernel.
-template <bool F32, bool EXT, int MODE>
+template <bool F32, bool EXT, int MODE, class PK>
 __global__ __launch_bounds__(BLOCK) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
                                                      long long ext_n, const int* __restrict__ ext_active,
                                                      const int* __restrict__ ext_partner, const double* __restrict__ ext_z,
                                                      const double* __restrict__ ext_logu) {
-    __shared__ WaveLds lds[WAVES_PER_BLOCK];
+    __shared__ WalkerLds<PK::KCAP> lds[WAVES_PER_BLOCK * PK::SUBS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub = lane / PK::LPW, l = lane % PK::LPW;
     const long long halfW = S.W >> 1;
-    long long slot = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const long long slot0 = ((long long)blockIdx.x * WAVES_PER_BLOCK + wave) * PK::SUBS;   // first walker of this wave
+    long long slot = slot0 + sub;
     int region;
     long long ws, wc;            // local walker ids (within the region) of mover and partner
     double z, logu;
@@ -530,7 +557,9 @@ __global__ __launch_bounds__(BLOCK) void k_half_step(SamplerDev S, PixPtrs px, u
     } else {
         slot += S.slot_begin;
         if (slot >= S.slot_end) return;
-        region = (int)(slot / halfW);
+        // every walker of a wave lies in one region (the host packs only when W/2 and the shard
+        // boundaries are multiples of SUBS): keep the region description in scalar registers
+        region = __builtin_amdgcn_readfirstlane((int)((slot0 + S.slot_begin) / halfW));
         const long long a_loc = slot - (long long)region * halfW;          // active slot inside the region
         const unsigned hb = (unsigned)(S.split_block >> 1);
         const unsigned chunk = (unsigned)(a_loc / hb);
@@ -553,22 +582,22 @@ __global__ __launch_bounds__(BLOCK) void k_half_step(SamplerDev S, PixPtrs px, u
         logu = u2 > 0.0 ? log(u2) : NEG_INF;
     }
     const RegionDev R = S.regions[region];
-    WaveLds& L = lds[wave];
+    WalkerLds<PK::KCAP>& L = lds[wave * PK::SUBS + sub];
     double* Xs = S.X + R.theta_off + ws * R.D;
     const double* Xc = S.X + R.theta_off + wc * R.D;
-    for (int d = lane; d < R.D; d += 64) {
+    for (int d = l; d < R.D; d += PK::LPW) {
         const double c = Xc[d];
         L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
     }
     __builtin_amdgcn_wave_barrier();
-    const double lnp_q = wave_lnprob<F32, MODE>(R, L, px, lane, nullptr);
+    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, px, l, nullptr);
     const long long wg = R.walker_off + ws;
     const double lnp_s = S.lnp[wg];
     const double diff = (double)(R.D - 1) * log(z) + lnp_q - lnp_s;
     const bool accept = logu < diff;                      // false for NaN
     if (accept) {
-        for (int d = lane; d < R.D; d += 64) Xs[d] = L.theta[d];
-        if (lane == 0) {
+        for (int d = l; d < R.D; d += PK::LPW) Xs[d] = L.theta[d];
+        if (l == 0) {
             S.lnp[wg] = lnp_q;
             S.n_accept[wg] += 1;
         }
@@ -592,12 +621,19 @@ int fail(int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                   \
     } while (0)
 
-// run STMT with `M` bound to the compile-time parameterisation that matches runtime `mode`
-#define VAMP_FOR_MODE(mode, STMT)                                        \
-    do {                                                                 \
-        if ((mode) == VAMP_GAUSS3) { constexpr int M = VAMP_GAUSS3; STMT; } \
-        else if ((mode) == VAMP_VOIGT4) { constexpr int M = VAMP_VOIGT4; STMT; } \
-        else { constexpr int M = VAMP_NBZ3; STMT; }                      \
+// run the statement with `M` bound to the compile-time parameterisation that matches runtime
+// `mode` and `PK` to the packing (small = <16 lanes, 8 lines> per walker, else <64, 16>)
+#define VAMP_FOR_MODE_(mode, ...)                                               \
+    do {                                                                        \
+        if ((mode) == VAMP_GAUSS3) { constexpr int M = VAMP_GAUSS3; __VA_ARGS__; } \
+        else if ((mode) == VAMP_VOIGT4) { constexpr int M = VAMP_VOIGT4; __VA_ARGS__; } \
+        else { constexpr int M = VAMP_NBZ3; __VA_ARGS__; }                      \
+    } while (0)
+#define VAMP_FOR_MODE(mode, ...) VAMP_FOR_MODE_(mode, __VA_ARGS__)
+#define VAMP_FOR_MODE_PK(mode, small, ...)                                      \
+    do {                                                                        \
+        if (small) { using PK = PackSmall; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        else { using PK = PackWide; VAMP_FOR_MODE_(mode, __VA_ARGS__); }        \
     } while (0)
 
 }  // namespace
@@ -612,6 +648,8 @@ struct vamp_ctx {
     // regions
     int n_regions = 0;
     int mode = VAMP_VOIGT4;
+    int packing = 0;       // requested: 0 = auto, 16 or 64 lanes per walker
+    bool packed = false;   // regions qualify for <16, 8> (every K <= 8, short regions)
     std::vector<RegionDev> regions_h;
     RegionDev* regions_d = nullptr;
     long long n_pix = 0;
@@ -697,7 +735,14 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     S.slot_end = c->slot_end;
     const long long n = ext ? ext_n : (c->slot_end - c->slot_begin);
     if (n <= 0) return 0;
-    const unsigned grid = (unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    // <16 lanes, 8 lines> packing needs every wave inside one region and one shard
+    const int subs = PackSmall::SUBS;
+    // (automatic mode packs only launches big enough to fill the chip four walkers to a wave:
+    // below that a wave per walker has the shorter critical path)
+    const bool small = c->packed && !ext && (c->W / 2) % subs == 0 && (c->split_block / 2) % subs == 0 &&
+                       (c->packing == 16 || n >= PACK_MIN_WALKERS);
+    const long long per_block = (long long)WAVES_PER_BLOCK * (small ? subs : 1);
+    const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev.size()) {
@@ -720,19 +765,19 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     const PixPtrs px = c->pix();
     if (ext) {
         if (c->f32)
-            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_half_step<true, true, M>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<true, true, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
                                                       half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d));
         else
-            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_half_step<false, true, M>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<false, true, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
                                                       half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d));
     } else {
         const int* ni = nullptr;
         const double* nd = nullptr;
         if (c->f32)
-            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_half_step<true, false, M>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<true, false, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
                                                       half, 0, 0ll, ni, ni, nd, nd));
         else
-            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_half_step<false, false, M>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<false, false, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
                                                       half, 0, 0ll, ni, ni, nd, nd));
     }
     HIP_TRY(hipGetLastError());
@@ -799,6 +844,14 @@ int vamp_ctx_set_stream(vamp_ctx* c, void* hip_stream) {
     if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_set_stream: ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return VAMP_OK;
+}
+
+int vamp_ctx_set_packing(vamp_ctx* c, int lanes_per_walker) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: ctx is NULL");
+    if (lanes_per_walker != 0 && lanes_per_walker != 16 && lanes_per_walker != 64)
+        return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: lanes_per_walker must be 0 (auto), 16 or 64");
+    c->packing = lanes_per_walker;
     return VAMP_OK;
 }
 
@@ -893,6 +946,19 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
     }
     HIP_TRY(hipMalloc(&c->regions_d, n_regions * sizeof(RegionDev)));
     HIP_TRY(hipMemcpy(c->regions_d, R.data(), n_regions * sizeof(RegionDev), hipMemcpyHostToDevice));
+    {
+        int kmax = 0;
+        for (int r = 0; r < n_regions; ++r) kmax = std::max(kmax, R[r].K);
+        const double mean_p = (double)pix_off[n_regions] / n_regions;
+        if (c->packing == 16) {
+            if (kmax > PackSmall::KCAP) return fail(VAMP_ERR_ARG, "vamp_set_regions: 16-lane packing supports at most 8 components per region");
+            c->packed = true;
+        } else if (c->packing == 64) {
+            c->packed = false;
+        } else {
+            c->packed = kmax <= PackSmall::KCAP && mean_p <= 128.0;
+        }
+    }
     c->regions_h = R;
     c->mode = mode;
     c->n_regions = n_regions;
@@ -919,12 +985,14 @@ int vamp_lnprob(vamp_ctx* c, int region, int64_t W, const double* theta, double*
     HIP_TRY(hipMalloc(&lp_d, (size_t)W * sizeof(double)));
     if (chi2) HIP_TRY(hipMalloc(&ch_d, (size_t)W * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(th_d, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    const unsigned grid = (unsigned)((W + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    const bool small = c->packed && (c->packing == 16 || W >= PACK_MIN_WALKERS);
+    const long long per_block = (long long)WAVES_PER_BLOCK * (small ? PackSmall::SUBS : 1);
+    const unsigned grid = (unsigned)((W + per_block - 1) / per_block);
     if (c->f32)
-        VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_lnprob<true, M>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region,
+        VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region,
                                                   c->pix(), (long long)W, th_d, lp_d, ch_d));
     else
-        VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_lnprob<false, M>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region,
+        VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region,
                                                   c->pix(), (long long)W, th_d, lp_d, ch_d));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(lnprob, lp_d, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1047,13 +1115,15 @@ int vamp_sampler_init(vamp_ctx* c, int64_t W, const double* theta0, uint64_t see
     // initial log-posteriors of every walker
     for (int r = 0; r < c->n_regions; ++r) {
         const RegionDev& R = c->regions_h[r];
-        const unsigned grid = (unsigned)((W + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+        const bool small = c->packed && (c->packing == 16 || W >= PACK_MIN_WALKERS);
+        const long long per_block = (long long)WAVES_PER_BLOCK * (small ? PackSmall::SUBS : 1);
+        const unsigned grid = (unsigned)((W + per_block - 1) / per_block);
         double* nochi = nullptr;
         if (c->f32)
-            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_lnprob<true, M>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r,
                                                       c->pix(), (long long)W, c->X_d + R.theta_off, c->lnp_d + R.walker_off, nochi));
         else
-            VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_lnprob<false, M>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r,
                                                       c->pix(), (long long)W, c->X_d + R.theta_off, c->lnp_d + R.walker_off, nochi));
         HIP_TRY(hipGetLastError());
     }

@@ -79,6 +79,11 @@ class HipContext:
     def synchronize(self):
         _lib.check(self._lib.vamp_ctx_synchronize(self._h))
 
+    def set_packing(self, lanes_per_walker):
+        """0 = automatic, 16 = four walkers per wavefront (<= 8 components), 64 = one walker per
+        wavefront.  Applies from the next set_regions call."""
+        _lib.check(self._lib.vamp_ctx_set_packing(self._h, int(lanes_per_walker)))
+
     # -- data ----------------------------------------------------------------------------
     def set_regions(self, xs, fluxes, noises, n_comp, mode=MODE_VOIGT4, sample_sd=False, include_norm=False,
                     bounds=None, nbz=None):
