@@ -20,3 +20,6 @@ extern "C" void jfrac8_host(int64_t n, const double* x, const double* y, double*
     for (int64_t i = 0; i < n; ++i)
         out[i] = vamp::INV_SQRT_PI * vamp::voigt_jfrac<8>(fabs(x[i]), y[i], x[i] * x[i] + y[i] * y[i]);
 }
+extern "C" void exp_taylor_host(int64_t n, const double* a, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = vamp::exp_taylor(a[i]);
+}

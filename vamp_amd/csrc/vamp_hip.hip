@@ -314,7 +314,7 @@ __device__ __forceinline__ double sweep_f64(const RegionDev& R, const WalkerLds<
         }
 #pragma unroll
         for (int t = 0; t < TPIX; ++t) {
-            const double m = exp(-tau[t]);
+            const double m = vamp::exp_taylor(-tau[t]);
             const double r = (f[idx[t]] - m) * wt[idx[t]];
             const bool live = (base + LPW * t + lane) < P;
             chi += live ? r * r : 0.0;

@@ -71,11 +71,45 @@ VAMP_DEV double rcp_nr(double d) {
 #endif
 }
 
+// 1/k!.  Every series below (e^{-d^2}, cosh d, sinh d, cos, sin, the exp kernel) is a Taylor
+// polynomial written on these SAME literals: fp64 literals live in SGPR pairs on gfx950 (VOP3 takes
+// no 64-bit immediate), the near-axis branch alone would otherwise need > 100 SGPRs of them, and
+// the compiler spills what does not fit to VGPR lanes inside the pixel loop.
+constexpr double F2 = 0.5, F3 = 1.6666666666666666e-01, F4 = 4.1666666666666664e-02, F5 = 8.3333333333333332e-03,
+                 F6 = 1.3888888888888889e-03, F7 = 1.9841269841269841e-04, F8 = 2.4801587301587302e-05,
+                 F9 = 2.7557319223985893e-06, F10 = 2.7557319223985888e-07, F11 = 2.5052108385441720e-08,
+                 F12 = 2.0876756987868100e-09, F13 = 1.6059043836821613e-10, F14 = 1.1470745597729725e-11,
+                 F15 = 7.6471637318198164e-13, F16 = 4.7794773323873853e-14, F17 = 2.8114572543455206e-15;
+
+// e^a for a <= 0 (any finite a works): n = rint(a log2 e), r = a - n ln2 in two parts, degree-13
+// Taylor kernel on |r| <= 0.347 (truncation 4e-18), v_ldexp.  ~1 ulp; underflows to 0 like exp.
+VAMP_DEV double exp_taylor(double a) {
+    a = (a < -800.0) ? -800.0 : a;                             // e^-800 = 0 in fp64; keeps -inf finite, NaN stays NaN
+    const double n = rint(a * 1.4426950408889634074);
+    double r = fma(-n, 6.93147180369123816490e-01, a);         // ln2, leading bits (n*hi exact)
+    r = fma(-n, 1.90821492927058770002e-10, r);                // ln2 - hi
+    double p = F13;
+    p = fma(p, r, F12);
+    p = fma(p, r, F11);
+    p = fma(p, r, F10);
+    p = fma(p, r, F9);
+    p = fma(p, r, F8);
+    p = fma(p, r, F7);
+    p = fma(p, r, F6);
+    p = fma(p, r, F5);
+    p = fma(p, r, F4);
+    p = fma(p, r, F3);
+    p = fma(p, r, F2);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);                                   // NaN in: n = NaN -> p = NaN out
+}
+
 // exp(-x^2) with the rounding error of x*x folded back in (x up to ~27 before underflow matters)
 VAMP_DEV double exp_neg_sq(double x) {
     double s = x * x;
     double e = fma(x, x, -s);
-    return exp(-s) * (1.0 - e);
+    return exp_taylor(-s) * (1.0 - e);
 }
 
 // cos(a) for |a| < ~1e3 (the near-axis rule needs |a| = 2xy <= 72): two-part pi/2 reduction and
@@ -85,25 +119,25 @@ VAMP_DEV double cos_small(double a) {
     const double k = rint(a * 0.63661977236758138243);          // 2/pi
     double r = fma(-k, 1.57079632673412561417e+00, a);          // pi/2, leading 33 bits (k*hi exact)
     r = fma(-k, 6.07710050650619224932e-11, r);                 // pi/2 - hi
-    const double r2 = r * r;
-    double c = 4.779477332387385e-14;                           // 1/16!
-    c = fma(c, r2, -1.1470745597729725e-11);
-    c = fma(c, r2, 2.08767569878681e-09);
-    c = fma(c, r2, -2.755731922398589e-07);
-    c = fma(c, r2, 2.48015873015873e-05);
-    c = fma(c, r2, -1.3888888888888889e-03);
-    c = fma(c, r2, 4.1666666666666664e-02);
-    c = fma(c, r2, -0.5);
-    c = fma(c, r2, 1.0);                                        // cos r
-    double sn = 2.8114572543455206e-15;                         // 1/17!
-    sn = fma(sn, r2, -7.647163731819816e-13);
-    sn = fma(sn, r2, 1.6059043836821613e-10);
-    sn = fma(sn, r2, -2.505210838544172e-08);
-    sn = fma(sn, r2, 2.7557319223985893e-06);
-    sn = fma(sn, r2, -1.984126984126984e-04);
-    sn = fma(sn, r2, 8.333333333333333e-03);
-    sn = fma(sn, r2, -1.6666666666666666e-01);
-    sn = fma(sn * r2, r, r);                                    // sin r
+    const double m = -(r * r);
+    double c = F16;
+    c = fma(c, m, F14);
+    c = fma(c, m, F12);
+    c = fma(c, m, F10);
+    c = fma(c, m, F8);
+    c = fma(c, m, F6);
+    c = fma(c, m, F4);
+    c = fma(c, m, F2);
+    c = fma(c, m, 1.0);                                         // cos r
+    double sn = F17;
+    sn = fma(sn, m, F15);
+    sn = fma(sn, m, F13);
+    sn = fma(sn, m, F11);
+    sn = fma(sn, m, F9);
+    sn = fma(sn, m, F7);
+    sn = fma(sn, m, F5);
+    sn = fma(sn, m, F3);
+    sn = fma(sn * m, r, r);                                     // sin r
     const int q = (int)k & 3;                                   // cos(r + q pi/2)
     const double v = (q & 1) ? sn : c;
     return (q == 1 || q == 2) ? -v : v;
@@ -247,49 +281,52 @@ VAMP_DEV double voigt_core(double x, double y, const double* dtab, double pole, 
     const double d = x - (n0 + 0.5) * CORE_H;            // |d| <= h/2
     const double d2 = d * d;
     // e^{-d^2}, e^{+d}, e^{-d} by short series (|d| <= 0.25)
-    double g0 = 2.7557319223985893e-06;                  // 1/9!
-    g0 = fma(g0, -d2, 2.4801587301587302e-05);
-    g0 = fma(g0, -d2, 1.9841269841269841e-04);
-    g0 = fma(g0, -d2, 1.3888888888888889e-03);
-    g0 = fma(g0, -d2, 8.3333333333333332e-03);
-    g0 = fma(g0, -d2, 4.1666666666666664e-02);
-    g0 = fma(g0, -d2, 1.6666666666666666e-01);
-    g0 = fma(g0, -d2, 0.5);
-    g0 = fma(g0, -d2, 1.0);
-    g0 = fma(g0, -d2, 1.0);                              // exp(-d^2)
-    double ch = 1.1470745597729725e-11;                  // 1/14!
-    ch = fma(ch, d2, 2.08767569878681e-09);              // 1/12!
-    ch = fma(ch, d2, 2.755731922398589e-07);             // 1/10!
-    ch = fma(ch, d2, 2.48015873015873e-05);              // 1/8!
-    ch = fma(ch, d2, 1.3888888888888889e-03);            // 1/6!
-    ch = fma(ch, d2, 4.1666666666666664e-02);            // 1/4!
-    ch = fma(ch, d2, 0.5);
+    const double md2 = -d2;
+    double g0 = F9;
+    g0 = fma(g0, md2, F8);
+    g0 = fma(g0, md2, F7);
+    g0 = fma(g0, md2, F6);
+    g0 = fma(g0, md2, F5);
+    g0 = fma(g0, md2, F4);
+    g0 = fma(g0, md2, F3);
+    g0 = fma(g0, md2, F2);
+    g0 = fma(g0, md2, 1.0);
+    g0 = fma(g0, md2, 1.0);                              // exp(-d^2)
+    double ch = F14;
+    ch = fma(ch, d2, F12);
+    ch = fma(ch, d2, F10);
+    ch = fma(ch, d2, F8);
+    ch = fma(ch, d2, F6);
+    ch = fma(ch, d2, F4);
+    ch = fma(ch, d2, F2);
     ch = fma(ch, d2, 1.0);                               // cosh d
-    double sh = 7.647163731819816e-13;                   // 1/15!
-    sh = fma(sh, d2, 1.6059043836821613e-10);            // 1/13!
-    sh = fma(sh, d2, 2.505210838544172e-08);             // 1/11!
-    sh = fma(sh, d2, 2.7557319223985893e-06);            // 1/9!
-    sh = fma(sh, d2, 1.984126984126984e-04);             // 1/7!
-    sh = fma(sh, d2, 8.333333333333333e-03);             // 1/5!
-    sh = fma(sh, d2, 1.6666666666666666e-01);            // 1/3!
+    double sh = F15;
+    sh = fma(sh, d2, F13);
+    sh = fma(sh, d2, F11);
+    sh = fma(sh, d2, F9);
+    sh = fma(sh, d2, F7);
+    sh = fma(sh, d2, F5);
+    sh = fma(sh, d2, F3);
     sh = fma(sh, d2, 1.0) * d;                           // sinh d
     const double q = ch + sh, qi = ch - sh;              // e^{d}, e^{-d}   (h = 1/2: e^{2 d h})
-    constexpr double CJ[CORE_J] = {
-        7.78800783071404878e-01, 3.67879441171442334e-01, 1.05399224561864333e-01,
-        1.83156388887341787e-02, 1.93045413622770930e-03, 1.23409804086679561e-04,
-        4.78511739212900875e-06, 1.12535174719259116e-07, 1.60522805518561165e-09,
-        1.38879438649640209e-11, 7.28772409581969219e-14, 2.31952283024356963e-16,
-        4.47773244171830150e-19};
     const double* p = dtab + n0 + DTAB_OFF;              // centre node; +-j are immediate offsets
-    // S = p0 + sum_j CJ_j (q^j p_j + q^-j p_-j): two Horner chains in q and 1/q (all terms
-    // positive), 4 instructions per node pair
-    double sp = CJ[CORE_J - 1] * p[CORE_J], sm = CJ[CORE_J - 1] * p[-CORE_J];
+    // S = p0 + sum_j c_j (q^j p_j + q^-j p_-j), c_j = e^{-j^2/4} = prod_{i<=j} rho_i, rho_i = e^{-(2i-1)/4}:
+    //   S+ = t_1 (p_1 + t_2 (p_2 + ... + t_13 p_13)),  t_j = q rho_j,  t_{j-1} = t_j e^{1/2}
+    // two Horner chains (q and 1/q), all terms positive, 4 instructions per node pair and only
+    // two literals (rho_13, e^{1/2}) instead of thirteen.
+    static_assert(CORE_J == 13, "rho_13 below is e^{-(2*13-1)/4}");
+    constexpr double RHO_TOP = 1.93045413622770930e-03;  // e^{-25/4}
+    constexpr double SQRT_E = 1.64872127070012819e+00;   // e^{1/2}
+    double tp = q * RHO_TOP, tm = qi * RHO_TOP;
+    double sp = p[CORE_J], sm = p[-CORE_J];
 #pragma unroll
-    for (int j = CORE_J - 1; j >= 1; --j) {
-        sp = fma(sp, q, CJ[j - 1] * p[j]);
-        sm = fma(sm, qi, CJ[j - 1] * p[-j]);
+    for (int j = CORE_J; j >= 2; --j) {
+        sp = fma(sp, tp, p[j - 1]);
+        sm = fma(sm, tm, p[-(j - 1)]);
+        tp *= SQRT_E;
+        tm *= SQRT_E;
     }
-    const double S = fma(sp, q, fma(sm, qi, p[0]));
+    const double S = fma(sp, tp, fma(sm, tm, p[0]));
     double H = hy * (g0 * S);
     if (pole != 0.0) H = fma(pole * exp_neg_sq(x), cos_small(2.0 * x * y), H);
     return H;
