@@ -80,12 +80,14 @@ struct LineRec {           // per (walker, component), lives in LDS
 // wave); KCAP bounds the lines per walker and so the LDS footprint.  <64,16> is the headline shape
 // (thousands of pixels per region); <16,8> serves the 9..478-pixel regions of real spectra, where
 // one walker cannot fill a wave and the per-walker fixed work (staging, draws, reduction) dominates.
-template <int LPW_, int KCAP_>
+template <int LPW_, int KCAP_, bool TAIL_>
 struct Pack {
     static constexpr int LPW = LPW_, KCAP = KCAP_, SUBS = 64 / LPW_;
+    static constexpr bool TAIL = TAIL_;     // false: every region is a whole number of full tiles
 };
-using PackWide = Pack<64, KMAX>;
-using PackSmall = Pack<16, 8>;
+using PackWide = Pack<64, KMAX, true>;
+using PackWideFull = Pack<64, KMAX, false>;   // the headline shape: no tail code, fewer registers
+using PackSmall = Pack<16, 8, true>;
 
 template <int KCAP>
 struct WalkerLds {
@@ -186,19 +188,21 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
 // the line centre; the wave takes the deepest branch any of its pixels needs (a deeper J-fraction
 // is valid wherever a shallower one is).  Only waves that straddle |z|^2 = 64 diverge.
 #ifndef VAMP_TPIX
-#define VAMP_TPIX 2
+#define VAMP_TPIX 4
 #endif
-constexpr int TPIX = VAMP_TPIX;      // pixels per lane per iteration
+constexpr int TPIX = VAMP_TPIX;      // pixels per lane per iteration in full tiles (the tail of a
+                                     // region runs one pixel per lane, so short regions waste nothing)
 
-template <int M>
-__device__ __forceinline__ void tile_jfrac(const double (&X)[TPIX], const double (&r2)[TPIX], double y, double (&H)[TPIX]) {
+template <int M, int T>
+__device__ __forceinline__ void tile_jfrac(const double (&X)[T], const double (&r2)[T], double y, double (&H)[T]) {
     int t = 0;
 #pragma unroll
-    for (; t + 1 < TPIX; t += 2) vamp::voigt_jfrac_x2<M>(X[t], X[t + 1], y, r2[t], r2[t + 1], H[t], H[t + 1]);
-    if (t < TPIX) H[t] = vamp::voigt_jfrac<M>(X[t], y, r2[t]);
+    for (; t + 1 < T; t += 2) vamp::voigt_jfrac_x2<M>(X[t], X[t + 1], y, r2[t], r2[t + 1], H[t], H[t + 1]);
+    if (t < T) H[t] = vamp::voigt_jfrac<M>(X[t], y, r2[t]);
 }
 
-__device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab, const double (&Xin)[TPIX], double (&H)[TPIX]) {
+template <int T>
+__device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab, const double (&Xin)[T], double (&H)[T]) {
     const double y = ln.y;
     const double y2 = y * y;
     // narrow line: |z| spans many units (possibly decades) inside one tile, and a lane promoted to a
@@ -206,20 +210,20 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
     // lanes beyond it are clamped into the range of the fractions here and get the closed far form
     // below.  One v_min per evaluation; the patch is a wave-uniform branch.
     const double xcap = ln.xcap;
-    double X[TPIX];
+    double X[T];
 #pragma unroll
-    for (int t = 0; t < TPIX; ++t) X[t] = fmin(Xin[t], xcap);
-    double r2[TPIX];
+    for (int t = 0; t < T; ++t) X[t] = fmin(Xin[t], xcap);
+    double r2[T];
     double lo;
 #pragma unroll
-    for (int t = 0; t < TPIX; ++t) {
+    for (int t = 0; t < T; ++t) {
         r2[t] = fma(X[t], X[t], y2);
         lo = t ? fmin(lo, r2[t]) : r2[0];
     }
 #ifdef VAMP_FORCE_TIER   // timing-only builds (tools/tier_cost.py): every tile takes one branch
     {
 #pragma unroll
-        for (int t = 0; t < TPIX; ++t) {
+        for (int t = 0; t < T; ++t) {
             const double xx = X[t] < 6.4 ? X[t] : 6.4;
             if (VAMP_FORCE_TIER == 0) H[t] = vamp::voigt_core(xx, y, dtab, ln.pole, ln.hy);
             else if (VAMP_FORCE_TIER == 1) H[t] = vamp::voigt_jfrac<6>(X[t], y, r2[t]);
@@ -237,56 +241,57 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
         if (__any(lo < vamp::R2_M4)) {
             if (__any(lo < vamp::R2_CORE)) {
 #pragma unroll
-                for (int t = 0; t < TPIX; ++t) {
+                for (int t = 0; t < T; ++t) {
                     if (r2[t] < vamp::R2_CORE) H[t] = vamp::voigt_core(X[t], y, dtab, ln.pole, ln.hy);
                     else H[t] = vamp::voigt_jfrac<6>(X[t], y, r2[t]);
                 }
                 if (y < vamp::Y_TINY) {
 #pragma unroll
-                    for (int t = 0; t < TPIX; ++t)
+                    for (int t = 0; t < T; ++t)
                         if (!(r2[t] < vamp::R2_CORE)) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
                 }
             } else {
-                tile_jfrac<6>(X, r2, y, H);
+                tile_jfrac<6, T>(X, r2, y, H);
                 if (y < vamp::Y_TINY) {
 #pragma unroll
-                    for (int t = 0; t < TPIX; ++t) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
+                    for (int t = 0; t < T; ++t) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
                 }
             }
         } else {
-            tile_jfrac<4>(X, r2, y, H);
+            tile_jfrac<4, T>(X, r2, y, H);
         }
     } else if (__any(lo < vamp::R2_M2)) {
-        tile_jfrac<3>(X, r2, y, H);
+        tile_jfrac<3, T>(X, r2, y, H);
     } else if (__any(lo < vamp::R2_M1)) {
-        tile_jfrac<2>(X, r2, y, H);
+        tile_jfrac<2, T>(X, r2, y, H);
     } else {
 #pragma unroll
-        for (int t = 0; t < TPIX; ++t) H[t] = vamp::voigt_far(Xin[t], y, fma(Xin[t], Xin[t], y2));
+        for (int t = 0; t < T; ++t) H[t] = vamp::voigt_far(Xin[t], y, fma(Xin[t], Xin[t], y2));
     }
     // (for |z|^2 >= 196 the missing e^{-x^2} is < 1e-85: no tiny-y correction needed there)
     if (xcap < __builtin_huge_val()) {
 #pragma unroll
-        for (int t = 0; t < TPIX; ++t)
+        for (int t = 0; t < T; ++t)
             if (Xin[t] > vamp::X_FAR) H[t] = vamp::voigt_far(Xin[t], y, fma(Xin[t], Xin[t], y2));
     }
 }
 
-// chi^2 sweep, fp64 pixel arithmetic.  Returns sum over the wave's pixels of ((f-m) w)^2.
-// A lane holds TPIX pixels (i, i+64, ...) per iteration: TPIX independent dependency chains and
-// one LDS read of the line record per TPIX evaluations.
-template <int MODE, class PK = PackWide>
-__device__ __forceinline__ double sweep_f64(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x,
-                                            const double* __restrict__ f, const double* __restrict__ wt, int lane) {
-    double chi = 0.0;
+// chi^2 sweep, fp64 pixel arithmetic.  Returns sum over the walker's pixels of ((f-m) w)^2.
+// Full tiles: a lane holds TPIX pixels (i, i+LPW, ...) per iteration -- TPIX independent dependency
+// chains and one LDS read of the line record per TPIX evaluations; the remaining pixels of the
+// region run one per lane.
+template <int MODE, class PK, int T>
+__device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x,
+                                            const double* __restrict__ f, const double* __restrict__ wt, int lane,
+                                            int base0, int base1, double& chi) {
     const int K = R.K, P = R.P;
     constexpr bool gauss = (MODE == VAMP_GAUSS3);
     constexpr int LPW = PK::LPW;
-    for (int base = 0; base < P; base += LPW * TPIX) {
-        double xi[TPIX], tau[TPIX];
-        int idx[TPIX];
+    for (int base = base0; base < base1; base += LPW * T) {
+        double xi[T], tau[T];
+        int idx[T];
 #pragma unroll
-        for (int t = 0; t < TPIX; ++t) {
+        for (int t = 0; t < T; ++t) {
             const int i = base + LPW * t + lane;
             idx[t] = i < P ? i : P - 1;          // tail lanes recompute the last pixel and drop it
             xi[t] = x[idx[t]];
@@ -296,7 +301,7 @@ __device__ __forceinline__ double sweep_f64(const RegionDev& R, const WalkerLds<
             for (int k = 0; k < K; ++k) {
                 const double c = L.line[k].c, s = L.line[k].s, a = L.line[k].amp;
 #pragma unroll
-                for (int t = 0; t < TPIX; ++t) {
+                for (int t = 0; t < T; ++t) {
                     const double u = (xi[t] - c) * s;
                     tau[t] += a * exp(-0.5 * (u * u));
                 }
@@ -304,23 +309,32 @@ __device__ __forceinline__ double sweep_f64(const RegionDev& R, const WalkerLds<
         } else {
             for (int k = 0; k < K; ++k) {
                 const LineRec ln = L.line[k];
-                double X[TPIX], H[TPIX];
+                double X[T], H[T];
 #pragma unroll
-                for (int t = 0; t < TPIX; ++t) X[t] = fabs(xi[t] - ln.c) * ln.s;
-                tile_voigt(ln, L.dtab[k], X, H);
+                for (int t = 0; t < T; ++t) X[t] = fabs(xi[t] - ln.c) * ln.s;
+                tile_voigt<T>(ln, L.dtab[k], X, H);
 #pragma unroll
-                for (int t = 0; t < TPIX; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
+                for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
             }
         }
 #pragma unroll
-        for (int t = 0; t < TPIX; ++t) {
+        for (int t = 0; t < T; ++t) {
             const double m = vamp::exp_taylor(-tau[t]);
             const double r = (f[idx[t]] - m) * wt[idx[t]];
             const bool live = (base + LPW * t + lane) < P;
             chi += live ? r * r : 0.0;
         }
     }
-    return wave_sum<LPW>(chi);
+}
+
+template <int MODE, class PK = PackWide>
+__device__ __forceinline__ double sweep_f64(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x,
+                                            const double* __restrict__ f, const double* __restrict__ wt, int lane) {
+    double chi = 0.0;
+    const int full = (R.P / (PK::LPW * TPIX)) * (PK::LPW * TPIX);
+    if (TPIX > 1) sweep_range<MODE, PK, TPIX>(R, L, x, f, wt, lane, 0, full, chi);
+    if constexpr (PK::TAIL || TPIX == 1) sweep_range<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, chi);
+    return wave_sum<PK::LPW>(chi);
 }
 
 // fp32 pixel arithmetic (Humlicek W4), chi^2 accumulated in fp64 (SURVEY section 7 hard parts).
@@ -633,6 +647,7 @@ int fail(int code, const std::string& msg) {
 #define VAMP_FOR_MODE_PK(mode, small, ...)                                      \
     do {                                                                        \
         if (small) { using PK = PackSmall; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        else if (c->full_tiles) { using PK = PackWideFull; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else { using PK = PackWide; VAMP_FOR_MODE_(mode, __VA_ARGS__); }        \
     } while (0)
 
@@ -650,6 +665,7 @@ struct vamp_ctx {
     int mode = VAMP_VOIGT4;
     int packing = 0;       // requested: 0 = auto, 16 or 64 lanes per walker
     bool packed = false;   // regions qualify for <16, 8> (every K <= 8, short regions)
+    bool full_tiles = false;   // every region's pixel count is a multiple of 64 * TPIX
     std::vector<RegionDev> regions_h;
     RegionDev* regions_d = nullptr;
     long long n_pix = 0;
@@ -958,6 +974,8 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         } else {
             c->packed = kmax <= PackSmall::KCAP && mean_p <= 128.0;
         }
+        c->full_tiles = true;
+        for (int r = 0; r < n_regions; ++r) c->full_tiles = c->full_tiles && (R[r].P % (64 * TPIX) == 0);
     }
     c->regions_h = R;
     c->mode = mode;
