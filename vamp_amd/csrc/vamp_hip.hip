@@ -338,30 +338,78 @@ __device__ __forceinline__ double sweep_f64(const RegionDev& R, const WalkerLds<
 }
 
 // fp32 pixel arithmetic (Humlicek W4), chi^2 accumulated in fp64 (SURVEY section 7 hard parts).
+// Same shape as the fp64 sweep: TPIX pixels per lane in full tiles and one wave-uniform region per
+// (tile, line) -- region I when every lane has s >= 15, region II (valid for all s >= 5.5) when
+// every lane has s >= 5.5, per-lane selection only for tiles that touch the line core.
+template <int T>
+__device__ __forceinline__ void tile_w4(float y, const float (&X)[T], float (&H)[T]) {
+    float lo = X[0];
+#pragma unroll
+    for (int t = 1; t < T; ++t) lo = fminf(lo, X[t]);
+    lo += y;
+    if (!__any(!(lo >= 15.0f))) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) H[t] = vamp::w4_region1(X[t], y);
+    } else if (!__any(!(lo >= 5.5f))) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) H[t] = vamp::w4_region2(X[t], y);
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) H[t] = vamp::humlicek_w4_re(X[t], y);
+    }
+}
+
+template <int MODE, class PK, int T>
+__device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const float* __restrict__ x,
+                                                const float* __restrict__ f, const float* __restrict__ wt, int lane,
+                                                int base0, int base1, double& chi) {
+    const int K = R.K, P = R.P;
+    constexpr bool gauss = (MODE == VAMP_GAUSS3);
+    constexpr int LPW = PK::LPW;
+    for (int base = base0; base < base1; base += LPW * T) {
+        float xi[T], tau[T];
+        int idx[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int i = base + LPW * t + lane;
+            idx[t] = i < P ? i : P - 1;
+            xi[t] = x[idx[t]];
+            tau[t] = 0.0f;
+        }
+        for (int k = 0; k < K; ++k) {
+            const float c = L.linef[k][0], s = L.linef[k][1], y = L.linef[k][2], a = L.linef[k][3];
+            if constexpr (gauss) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float u = (xi[t] - c) * s;
+                    tau[t] += a * __expf(-0.5f * (u * u));
+                }
+            } else {
+                float X[T], H[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) X[t] = fabsf(xi[t] - c) * s;
+                tile_w4<T>(y, X, H);
+#pragma unroll
+                for (int t = 0; t < T; ++t) tau[t] = fmaf(a, H[t], tau[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float m = __expf(-tau[t]);
+            const float r = (f[idx[t]] - m) * wt[idx[t]];
+            const bool live = (base + LPW * t + lane) < P;
+            chi += live ? (double)r * (double)r : 0.0;
+        }
+    }
+}
+
 template <int MODE, class PK = PackWide>
 __device__ __forceinline__ double sweep_f32(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const float* __restrict__ x,
                                             const float* __restrict__ f, const float* __restrict__ wt, int lane) {
     double chi = 0.0;
-    const int K = R.K, P = R.P;
-    constexpr bool gauss = (MODE == VAMP_GAUSS3);
-    for (int i = lane; i < P; i += PK::LPW) {
-        const float xi = x[i];
-        float tau = 0.0f;
-        if constexpr (gauss) {
-            for (int k = 0; k < K; ++k) {
-                const float u = (xi - L.linef[k][0]) * L.linef[k][1];
-                tau += L.linef[k][3] * __expf(-0.5f * (u * u));
-            }
-        } else {
-            for (int k = 0; k < K; ++k) {
-                const float X = fabsf(xi - L.linef[k][0]) * L.linef[k][1];
-                tau += L.linef[k][3] * vamp::humlicek_w4_re(X, L.linef[k][2]);
-            }
-        }
-        const float m = __expf(-tau);
-        const float r = (f[i] - m) * wt[i];
-        chi += (double)r * (double)r;
-    }
+    const int full = (R.P / (PK::LPW * TPIX)) * (PK::LPW * TPIX);
+    if (TPIX > 1) sweep_range_f32<MODE, PK, TPIX>(R, L, x, f, wt, lane, 0, full, chi);
+    if constexpr (PK::TAIL || TPIX == 1) sweep_range_f32<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, chi);
     return wave_sum<PK::LPW>(chi);
 }
 
@@ -484,7 +532,7 @@ __global__ __launch_bounds__(BLOCK) void k_wofz(long long n, const double* __res
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     if (F32) {
-        out[i] = (double)vamp::humlicek_w4_re(fabsf((float)x[i]), (float)y[i]);
+        out[i] = (double)vamp::humlicek_w4_re(fminf(fabsf((float)x[i]), vamp::W4_XMAX), (float)y[i]);
     } else {
         double dtab[vamp::DTAB_N];
         for (int k = 0; k < vamp::DTAB_N; ++k) dtab[k] = vamp::core_dtab_entry(k, y[i]);

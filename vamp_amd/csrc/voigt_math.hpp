@@ -368,42 +368,58 @@ VAMP_DEV double voigt_H(double x, double y, const double* dtab, double pole, dou
 }
 
 // ---- fp32: Humlicek W4 --------------------------------------------------------------------
-// Re w(x + i y), t = y - i x, s = |x| + y.  Complex arithmetic spelled out in floats.
+// Re w(x + i y), t = y - i x, s = |x| + y (JQSRT 27 (1982) 437).  Complex arithmetic spelled out in
+// floats; quotients through v_rcp_f32 (1 ulp, far inside the method's 1e-4).
+//   region I   s >= 15                       t 0.5641896 / (0.5 + t^2)
+//   region II  5.5 <= s < 15                 valid (and more accurate) for every s >= 5.5
+//   region III s < 5.5, y >= 0.195|x| - 0.176
+//   region IV  otherwise
 struct cf32 { float re, im; };
 VAMP_DEV cf32 cmul(cf32 a, cf32 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 VAMP_DEV cf32 cadd(cf32 a, float c) { return {a.re + c, a.im}; }
 VAMP_DEV cf32 cscale(cf32 a, float c) { return {a.re * c, a.im * c}; }
-VAMP_DEV float cdiv_re(cf32 n, cf32 d) {   // Re(n/d)
-    return (n.re * d.re + n.im * d.im) / (d.re * d.re + d.im * d.im);
+VAMP_DEV float rcp32(float d) {
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_rcpf(d);
+#else
+    return 1.0f / d;
+#endif
 }
+VAMP_DEV float cdiv_re(cf32 n, cf32 d) {   // Re(n/d)
+    return (n.re * d.re + n.im * d.im) * rcp32(d.re * d.re + d.im * d.im);
+}
+constexpr float W4_XMAX = 1.0e9f;          // beyond, x^4 leaves the fp32 range; H < 1e-18 y there
 
-VAMP_DEV float humlicek_w4_re(float x, float y) {
+VAMP_DEV float w4_region1(float x, float y) {
+    x = fminf(x, W4_XMAX);
     const cf32 t = {y, -x};
-    const float s = fabsf(x) + y;
-    if (s >= 15.0f) {                                  // region I
-        cf32 u = cmul(t, t);
-        return cdiv_re(cscale(t, 0.5641896f), cadd(u, 0.5f));
-    }
-    if (s >= 5.5f) {                                   // region II
-        cf32 u = cmul(t, t);
-        cf32 n = cmul(t, cadd(cscale(u, 0.5641896f), 1.410474f));
-        cf32 d = cadd(cmul(u, cadd(u, 3.0f)), 0.75f);
-        return cdiv_re(n, d);
-    }
-    if (y >= 0.195f * fabsf(x) - 0.176f) {             // region III
-        cf32 n = cadd(cscale(t, 0.5642236f), 3.778987f);
-        n = cadd(cmul(n, t), 11.96482f);
-        n = cadd(cmul(n, t), 20.20933f);
-        n = cadd(cmul(n, t), 16.4955f);
-        cf32 d = cadd(t, 6.699398f);
-        d = cadd(cmul(d, t), 21.69274f);
-        d = cadd(cmul(d, t), 39.27121f);
-        d = cadd(cmul(d, t), 38.82363f);
-        d = cadd(cmul(d, t), 16.4955f);
-        return cdiv_re(n, d);
-    }
-    // region IV
-    cf32 u = cmul(t, t);
+    const cf32 u = cmul(t, t);
+    return cdiv_re(cscale(t, 0.5641896f), cadd(u, 0.5f));
+}
+VAMP_DEV float w4_region2(float x, float y) {
+    x = fminf(x, 3.0e4f);                  // |d|^2 ~ x^8 must stay finite; region I takes over in value
+    const cf32 t = {y, -x};
+    const cf32 u = cmul(t, t);
+    const cf32 n = cmul(t, cadd(cscale(u, 0.5641896f), 1.410474f));
+    const cf32 d = cadd(cmul(u, cadd(u, 3.0f)), 0.75f);
+    return cdiv_re(n, d);
+}
+VAMP_DEV float w4_region3(float x, float y) {
+    const cf32 t = {y, -x};
+    cf32 n = cadd(cscale(t, 0.5642236f), 3.778987f);
+    n = cadd(cmul(n, t), 11.96482f);
+    n = cadd(cmul(n, t), 20.20933f);
+    n = cadd(cmul(n, t), 16.4955f);
+    cf32 d = cadd(t, 6.699398f);
+    d = cadd(cmul(d, t), 21.69274f);
+    d = cadd(cmul(d, t), 39.27121f);
+    d = cadd(cmul(d, t), 38.82363f);
+    d = cadd(cmul(d, t), 16.4955f);
+    return cdiv_re(n, d);
+}
+VAMP_DEV float w4_region4(float x, float y) {
+    const cf32 t = {y, -x};
+    const cf32 u = cmul(t, t);
     cf32 n = cadd(cscale(u, -0.56419f), 1.320522f);     // 1.320522 - u*0.56419
     n = cadd(cscale(cmul(u, n), -1.0f), 35.76683f);
     n = cadd(cscale(cmul(u, n), -1.0f), 219.0313f);
@@ -418,9 +434,16 @@ VAMP_DEV float humlicek_w4_re(float x, float y) {
     d = cadd(cscale(cmul(u, d), -1.0f), 9022.228f);
     d = cadd(cscale(cmul(u, d), -1.0f), 24322.84f);
     d = cadd(cscale(cmul(u, d), -1.0f), 32066.6f);
-    // exp(u) real part: e^{u.re} cos(u.im)
-    const float eu = expf(u.re) * cosf(u.im);
+    const float eu = expf(u.re) * cosf(u.im);           // Re exp(t^2)
     return eu - cdiv_re(n, d);
+}
+
+VAMP_DEV float humlicek_w4_re(float x, float y) {
+    const float s = fabsf(x) + y;
+    if (s >= 15.0f) return w4_region1(x, y);
+    if (s >= 5.5f) return w4_region2(x, y);
+    if (y >= 0.195f * fabsf(x) - 0.176f) return w4_region3(x, y);
+    return w4_region4(x, y);
 }
 
 }  // namespace vamp
