@@ -298,3 +298,41 @@ def test_full_size_properties(hip_ctx):
     want = vo.log_prob_batch_fast(r, small["theta0"])
     got = hip_ctx.lnprob(small["theta0"])
     assert np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) <= 1e-9
+
+
+def test_rare_branches_in_long_regions(hip_ctx):
+    """Data-dependent branches that the seeded fixtures only reach in one-tile regions, forced here
+    in a 4096-pixel region (64 tiles per line): a narrow line whose |z| spans decades inside one tile
+    (cap + closed far form), a line with y < 1e-9 (missing e^{-x^2} restored in every fraction
+    branch), a broad damped line (y > 4.5: no pole term), and a line centred off the grid."""
+    if hip_ctx.packing_request == 16:
+        pytest.skip("long region: one walker per wavefront")
+    rng = np.random.default_rng(77)
+    P = 4096
+    x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+    noise = np.full(P, 0.02)
+    flux = 1.0 + rng.normal(0, 0.02, P)
+    cases = np.array([
+        # A,    c,       L,       G
+        [1.2, -1500.3, 0.5, 0.04,      0.7, 200.7, 1e-12, 30.0,     2.0, 900.0, 400.0, 50.0,    0.9, 1800.25, 3.0, 9.0],
+        [0.4, 10.0, 1e-3, 1e-3,        1.5, -700.0, 2e-11, 5.0,     0.3, 0.0, 900.0, 120.0,     2.5, -2000.0, 40.0, 2.0],
+        [3.0, 2047.5, 0.02, 0.3,       0.2, -2047.5, 1e-10, 80.0,   1.0, 333.3, 2000.0, 300.0,  0.6, -10.0, 0.5, 700.0],
+    ])
+    hip_ctx.set_regions(x, flux, noise, 4, mode=vo.MODE_VOIGT4)
+    r = vo.Region(x=x, flux=flux, noise=noise, n_comp=4, mode=vo.MODE_VOIGT4)
+    want, wchi = vo.log_prob_batch(r, cases, return_chi2=True)
+    got, chi = hip_ctx.lnprob(cases, return_chi2=True)
+    assert np.isfinite(want).all()
+    assert np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) <= 1e-9
+    assert np.max(np.abs(chi - wchi) / wchi) <= 1e-11
+    for th in cases:
+        tau, fl = hip_ctx.model(th)
+        ref = vo.component_taus(r, th)
+        big = ref > 1e-280
+        assert np.max(np.abs(tau[big] - ref[big]) / ref[big]) <= 1e-12
+    # the same lines through the sampler kernel's sweep: the stored lnprob of an unmoved ensemble
+    X0 = np.repeat(cases, 8, axis=0)[:16] * (1 + 1e-9 * rng.standard_normal((16, 16)))
+    hip_ctx.sampler_init(X0, seed=3, split_block=16)
+    hip_ctx.run(2, store_chain=False)
+    X, lnp, nacc, _ = hip_ctx.get_state()
+    assert np.allclose(vo.log_prob_batch(r, X), lnp, rtol=1e-9, atol=1e-9)
