@@ -96,7 +96,7 @@ struct WalkerLds {
     double dtab[KCAP][vamp::DTAB_N];
     float linef[KCAP][4];  // fp32 path: c, s, y, amp
 };
-using WaveLds = WalkerLds<KMAX>;
+using WaveLds = WalkerLds<KMAX>;      // the one-walker-per-wavefront kernels (k_model, k_line_records)
 
 // ---------------------------------------------------------------------------------------
 // wave helpers
@@ -683,6 +683,13 @@ int fail(int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                   \
     } while (0)
 
+// device allocation released on every exit path of a host function
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 // run the statement with `M` bound to the compile-time parameterisation that matches runtime
 // `mode` and `PK` to the packing (small = <16 lanes, 8 lines> per walker, else <64, 16>)
 #define VAMP_FOR_MODE_(mode, ...)                                               \
@@ -732,6 +739,9 @@ struct vamp_ctx {
     long long* nacc_d = nullptr;
     long long slot_begin = 0, slot_end = 0;
     int shard_rank = 0, shard_world = 1;
+    // grow-only scratch of vamp_lnprob (the MAP optimiser calls it thousands of times with W = 1)
+    double *sc_th = nullptr, *sc_lp = nullptr, *sc_chi = nullptr;
+    size_t sc_th_cap = 0, sc_w_cap = 0;
     // scratch for the ext hook
     int *ext_act_d = nullptr, *ext_par_d = nullptr;
     double *ext_z_d = nullptr, *ext_lu_d = nullptr;
@@ -893,7 +903,8 @@ int vamp_ctx_destroy(vamp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     free_sampler(c);
     free_regions(c);
-    for (void* p : {(void*)c->ext_act_d, (void*)c->ext_par_d, (void*)c->ext_z_d, (void*)c->ext_lu_d})
+    for (void* p : {(void*)c->ext_act_d, (void*)c->ext_par_d, (void*)c->ext_z_d, (void*)c->ext_lu_d, (void*)c->sc_th,
+                    (void*)c->sc_lp, (void*)c->sc_chi})
         if (p) (void)hipFree(p);
     for (auto& p : c->ev) {
         (void)hipEventDestroy(p.first);
@@ -1046,11 +1057,23 @@ int vamp_lnprob(vamp_ctx* c, int region, int64_t W, const double* theta, double*
     if (W <= 0) return fail(VAMP_ERR_ARG, "vamp_lnprob: W must be positive");
     HIP_TRY(hipSetDevice(c->device));
     const int D = c->regions_h[region].D;
-    double *th_d = nullptr, *lp_d = nullptr, *ch_d = nullptr;
-    HIP_TRY(hipMalloc(&th_d, (size_t)W * D * sizeof(double)));
-    HIP_TRY(hipMalloc(&lp_d, (size_t)W * sizeof(double)));
-    if (chi2) HIP_TRY(hipMalloc(&ch_d, (size_t)W * sizeof(double)));
-    HIP_TRY(hipMemcpyAsync(th_d, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const size_t nth = (size_t)W * D;
+    if (c->sc_th_cap < nth) {
+        if (c->sc_th) (void)hipFree(c->sc_th);
+        c->sc_th = nullptr; c->sc_th_cap = 0;
+        HIP_TRY(hipMalloc(&c->sc_th, nth * sizeof(double)));
+        c->sc_th_cap = nth;
+    }
+    if (c->sc_w_cap < (size_t)W) {
+        if (c->sc_lp) (void)hipFree(c->sc_lp);
+        if (c->sc_chi) (void)hipFree(c->sc_chi);
+        c->sc_lp = c->sc_chi = nullptr; c->sc_w_cap = 0;
+        HIP_TRY(hipMalloc(&c->sc_lp, (size_t)W * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->sc_chi, (size_t)W * sizeof(double)));
+        c->sc_w_cap = (size_t)W;
+    }
+    double *th_d = c->sc_th, *lp_d = c->sc_lp, *ch_d = chi2 ? c->sc_chi : nullptr;
+    HIP_TRY(hipMemcpyAsync(th_d, theta, nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const bool small = c->packed && (c->packing == 16 || W >= PACK_MIN_WALKERS);
     const long long per_block = (long long)WAVES_PER_BLOCK * (small ? PackSmall::SUBS : 1);
     const unsigned grid = (unsigned)((W + per_block - 1) / per_block);
@@ -1064,9 +1087,6 @@ int vamp_lnprob(vamp_ctx* c, int region, int64_t W, const double* theta, double*
     HIP_TRY(hipMemcpyAsync(lnprob, lp_d, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (chi2) HIP_TRY(hipMemcpyAsync(chi2, ch_d, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(th_d);
-    (void)hipFree(lp_d);
-    if (ch_d) (void)hipFree(ch_d);
     return VAMP_OK;
 }
 
@@ -1076,10 +1096,11 @@ int vamp_model(vamp_ctx* c, int region, const double* theta1, double* tau_comp, 
     if (region < 0 || region >= c->n_regions) return fail(VAMP_ERR_ARG, "vamp_model: no such region");
     HIP_TRY(hipSetDevice(c->device));
     const RegionDev& R = c->regions_h[region];
-    double *th_d = nullptr, *tau_d = nullptr, *fl_d = nullptr;
-    HIP_TRY(hipMalloc(&th_d, R.D * sizeof(double)));
-    if (tau_comp) HIP_TRY(hipMalloc(&tau_d, (size_t)R.K * R.P * sizeof(double)));
-    if (flux_model) HIP_TRY(hipMalloc(&fl_d, (size_t)R.P * sizeof(double)));
+    DevBuf th_b, tau_b, fl_b;
+    HIP_TRY(hipMalloc(&th_b.p, R.D * sizeof(double)));
+    if (tau_comp) HIP_TRY(hipMalloc(&tau_b.p, (size_t)R.K * R.P * sizeof(double)));
+    if (flux_model) HIP_TRY(hipMalloc(&fl_b.p, (size_t)R.P * sizeof(double)));
+    double *th_d = th_b.as<double>(), *tau_d = tau_b.as<double>(), *fl_d = fl_b.as<double>();
     HIP_TRY(hipMemcpyAsync(th_d, theta1, R.D * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const unsigned grid = (unsigned)((R.P + BLOCK - 1) / BLOCK);
     VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_model<M>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region, c->pix(),
@@ -1088,9 +1109,6 @@ int vamp_model(vamp_ctx* c, int region, const double* theta1, double* tau_comp, 
     if (tau_comp) HIP_TRY(hipMemcpyAsync(tau_comp, tau_d, (size_t)R.K * R.P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (flux_model) HIP_TRY(hipMemcpyAsync(flux_model, fl_d, (size_t)R.P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(th_d);
-    if (tau_d) (void)hipFree(tau_d);
-    if (fl_d) (void)hipFree(fl_d);
     return VAMP_OK;
 }
 
@@ -1100,9 +1118,10 @@ int vamp_line_records(vamp_ctx* c, int region, const double* theta1, double* rec
     if (region < 0 || region >= c->n_regions) return fail(VAMP_ERR_ARG, "vamp_line_records: no such region");
     HIP_TRY(hipSetDevice(c->device));
     const RegionDev& R = c->regions_h[region];
-    double *th_d = nullptr, *rec_d = nullptr;
-    HIP_TRY(hipMalloc(&th_d, R.D * sizeof(double)));
-    HIP_TRY(hipMalloc(&rec_d, (5 * R.K + 1) * sizeof(double)));
+    DevBuf th_b, rec_b;
+    HIP_TRY(hipMalloc(&th_b.p, R.D * sizeof(double)));
+    HIP_TRY(hipMalloc(&rec_b.p, (5 * R.K + 1) * sizeof(double)));
+    double *th_d = th_b.as<double>(), *rec_d = rec_b.as<double>();
     HIP_TRY(hipMemcpyAsync(th_d, theta1, R.D * sizeof(double), hipMemcpyHostToDevice, c->stream));
     VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_line_records<M>), dim3(1), dim3(64), 0, c->stream, c->regions_d, region, th_d,
                                               rec_d, rec_d + 5 * R.K));
@@ -1110,18 +1129,17 @@ int vamp_line_records(vamp_ctx* c, int region, const double* theta1, double* rec
     HIP_TRY(hipMemcpyAsync(rec, rec_d, 5 * R.K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(lnprior, rec_d + 5 * R.K, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(th_d);
-    (void)hipFree(rec_d);
     return VAMP_OK;
 }
 
 int vamp_wofz_re(vamp_ctx* c, int64_t n, const double* x, const double* y, double* re_w) {
     if (!c || !x || !y || !re_w || n <= 0) return fail(VAMP_ERR_ARG, "vamp_wofz_re: bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    double *x_d = nullptr, *y_d = nullptr, *o_d = nullptr;
-    HIP_TRY(hipMalloc(&x_d, n * sizeof(double)));
-    HIP_TRY(hipMalloc(&y_d, n * sizeof(double)));
-    HIP_TRY(hipMalloc(&o_d, n * sizeof(double)));
+    DevBuf x_b, y_b, o_b;
+    HIP_TRY(hipMalloc(&x_b.p, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&y_b.p, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&o_b.p, n * sizeof(double)));
+    double *x_d = x_b.as<double>(), *y_d = y_b.as<double>(), *o_d = o_b.as<double>();
     HIP_TRY(hipMemcpyAsync(x_d, x, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(y_d, y, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
@@ -1130,9 +1148,6 @@ int vamp_wofz_re(vamp_ctx* c, int64_t n, const double* x, const double* y, doubl
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(re_w, o_d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(x_d);
-    (void)hipFree(y_d);
-    (void)hipFree(o_d);
     return VAMP_OK;
 }
 
@@ -1286,9 +1301,10 @@ int vamp_sampler_run(vamp_ctx* c, int64_t n_steps, int thin, double* chain, doub
     if (c->shard_world != 1) return fail(VAMP_ERR_STATE, "vamp_sampler_run: sharded contexts are stepped by the host (half_step + all-gather)");
     HIP_TRY(hipSetDevice(c->device));
     const long long n_keep = n_steps / thin;
-    double *chain_d = nullptr, *lchain_d = nullptr;
-    if (chain && n_keep) HIP_TRY(hipMalloc(&chain_d, (size_t)n_keep * c->total_theta * sizeof(double)));
-    if (lnprob_chain && n_keep) HIP_TRY(hipMalloc(&lchain_d, (size_t)n_keep * c->total_walkers * sizeof(double)));
+    DevBuf chain_b, lchain_b;
+    if (chain && n_keep) HIP_TRY(hipMalloc(&chain_b.p, (size_t)n_keep * c->total_theta * sizeof(double)));
+    if (lnprob_chain && n_keep) HIP_TRY(hipMalloc(&lchain_b.p, (size_t)n_keep * c->total_walkers * sizeof(double)));
+    double *chain_d = chain_b.as<double>(), *lchain_d = lchain_b.as<double>();
     HIP_TRY(hipStreamSynchronize(c->stream));
     const auto t0 = std::chrono::steady_clock::now();
     long long kept = 0;
@@ -1313,11 +1329,9 @@ int vamp_sampler_run(vamp_ctx* c, int64_t n_steps, int thin, double* chain, doub
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
     if (chain_d) {
         HIP_TRY(hipMemcpy(chain, chain_d, (size_t)n_keep * c->total_theta * sizeof(double), hipMemcpyDeviceToHost));
-        (void)hipFree(chain_d);
     }
     if (lchain_d) {
         HIP_TRY(hipMemcpy(lnprob_chain, lchain_d, (size_t)n_keep * c->total_walkers * sizeof(double), hipMemcpyDeviceToHost));
-        (void)hipFree(lchain_d);
     }
     if (n_accept) HIP_TRY(hipMemcpy(n_accept, c->nacc_d, c->total_walkers * sizeof(long long), hipMemcpyDeviceToHost));
     return VAMP_OK;
