@@ -16,10 +16,6 @@ extern "C" void humlicek_w4_host(int64_t n, const float* x, const float* y, floa
 extern "C" void cos_small_host(int64_t n, const double* a, double* out) {
     for (int64_t i = 0; i < n; ++i) out[i] = vamp::cos_small(a[i]);
 }
-extern "C" void jfrac8_host(int64_t n, const double* x, const double* y, double* out) {
-    for (int64_t i = 0; i < n; ++i)
-        out[i] = vamp::INV_SQRT_PI * vamp::voigt_jfrac<8>(fabs(x[i]), y[i], x[i] * x[i] + y[i] * y[i]);
-}
 extern "C" void exp_taylor_host(int64_t n, const double* a, double* out) {
     for (int64_t i = 0; i < n; ++i) out[i] = vamp::exp_taylor(a[i]);
 }

@@ -54,3 +54,27 @@ if __name__ == "__main__":
         print("Q%d = {" % m + ", ".join(repr(float(c)) for c in Q) + "}")
     print("// c_j = exp(-j^2/4), j = 1..13")
     print(", ".join("%.17e" % math.exp(-0.25 * j * j) for j in range(1, 14)))
+
+
+def gh_partial_fractions(m, dps=60):
+    """K_m(zeta) = sum_j c_j / (zeta - zeta_j): poles = roots of Q_m (squares of the positive
+    Gauss-Hermite nodes of order 2m), residues c_j = P_{m-1}(zeta_j) / Q_m'(zeta_j) > 0."""
+    import mpmath as mp
+    mp.mp.dps = dps
+    P, Q = jfrac_polys(m)
+    Pm = [mp.mpf(c.numerator) / mp.mpf(c.denominator) for c in P]
+    Qm = [mp.mpf(c.numerator) / mp.mpf(c.denominator) for c in Q]
+    roots = mp.polyroots(Qm[::-1], maxsteps=500, extraprec=200)
+    roots = sorted(mp.re(r) for r in roots)
+    dQ = [k * Qm[k] for k in range(1, len(Qm))]
+    ev = lambda c, z: sum(ck * z ** k for k, ck in enumerate(c))
+    return [(z, ev(Pm, z) / ev(dQ, z)) for z in roots]
+
+
+if __name__ == "__main__":
+    print("// partial fractions of K_m: zeta_j, c_j  (c_j > 0, sum c_j = 1)")
+    for m in (2, 3, 4, 6):
+        pf = gh_partial_fractions(m)
+        print("// m =", m, " sum c =", float(sum(c for _, c in pf)))
+        print("Z%d = {" % m + ", ".join("%.17e" % float(z) for z, _ in pf) + "}")
+        print("C%d = {" % m + ", ".join("%.17e" % float(c) for _, c in pf) + "}")

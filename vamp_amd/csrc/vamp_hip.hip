@@ -231,7 +231,6 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
             else if (VAMP_FORCE_TIER == 3) H[t] = vamp::voigt_jfrac<3>(X[t], y, r2[t]);
             else if (VAMP_FORCE_TIER == 4) H[t] = vamp::voigt_jfrac<2>(X[t], y, r2[t]);
             else if (VAMP_FORCE_TIER == 5) H[t] = vamp::voigt_far(X[t], y, r2[t]);
-            else if (VAMP_FORCE_TIER == 7) H[t] = vamp::voigt_jfrac<8>(X[t], y, r2[t]);
             else H[t] = X[t] * y;
         }
         return;

@@ -158,93 +158,74 @@ VAMP_DEV double core_pole_factor(double y) {      // sqrt(pi) * A(y)
 VAMP_DEV double core_hy(double y) { return (CORE_H * INV_SQRT_PI) * y; }
 
 // ---- J-fraction tiers -------------------------------------------------------------------
-// sqrt(pi) Re[ i z P(zeta) / (sqrt(pi) Q(zeta)) ] = (ar*qi - ai*qr) / |Q|^2,  a = z P
-// P, Q are monic with real coefficients; they are evaluated at the complex point zeta with the
-// real-coefficient (Goertzel/Knuth) recurrence, 2 FMAs per coefficient:
-//   u_N = 1, u_{N-1} = a_{N-1} + r, u_j = a_j + r u_{j+1} - s u_{j+2},  r = 2 Re zeta, s = |zeta|^2
-//   p(zeta) = zeta u_1 + (a_0 - s u_2)
-template <int M> struct JFrac;
-template <> struct JFrac<2> {
-    static constexpr int NP = 1, NQ = 2;
-    static constexpr double P[1] = {-2.5};
-    static constexpr double Q[2] = {0.75, -3.0};
+// Working form of the fractions: K_m has simple real poles zeta_j > 0 (the squares of the positive
+// Gauss-Hermite nodes of order 2m) with positive residues c_j, and for z = x + i y
+//     -Im[ z / (z^2 - zeta_j) ] = y (|z|^2 + zeta_j) / |z^2 - zeta_j|^2 ,
+// so   sqrt(pi) Re w = y sum_j c_j (r2 + zeta_j) / D_j ,  D_j = r2^2 - 2 zeta_j Re(z^2) + zeta_j^2 :
+// m real Lorentzian-like terms put over one denominator (3 instructions per extra term), every
+// term positive -- no complex arithmetic, no cancellation, one reciprocal.  For |z|^2 >= 64 the
+// D_j are far from their zeros (zeta_j <= 15.2).  (Constants: tools/gen_voigt_tables.py.)
+template <int M> struct GHFrac;
+template <> struct GHFrac<2> {
+    static constexpr double Z[2] = {2.75255128608410948e-01, 2.72474487139158894e+00};
+    static constexpr double C[2] = {9.08248290463863017e-01, 9.17517095361369828e-02};
 };
-template <> struct JFrac<3> {
-    static constexpr int NP = 2, NQ = 3;
-    static constexpr double P[2] = {8.25, -7.0};
-    static constexpr double Q[3] = {-1.875, 11.25, -7.5};
+template <> struct GHFrac<3> {
+    static constexpr double Z[3] = {1.90163509193488123e-01, 1.78449274854325157e+00, 5.52534374226326008e+00};
+    static constexpr double C[3] = {8.17656939112058501e-01, 1.77231492083829045e-01, 5.11156880411249310e-03};
 };
-template <> struct JFrac<4> {
-    static constexpr int NP = 3, NQ = 4;
-    static constexpr double P[3] = {-34.875, 46.25, -13.5};
-    static constexpr double Q[4] = {6.5625, -52.5, 52.5, -14.0};
+template <> struct GHFrac<4> {
+    static constexpr double Z[4] = {1.45303521503317101e-01, 1.33909728812636142e+00, 3.92696350135828709e+00,
+                                    8.58863568901203500e+00};
+    static constexpr double C[4] = {7.46024515358154727e-01, 2.34479815323518026e-01, 1.92704402415765329e-02,
+                                    2.25229076750735536e-04};
 };
-template <> struct JFrac<6> {
-    static constexpr int NP = 5, NQ = 6;
-    static constexpr double P[5] = {-1115.15625, 2605.3125, -1569.75, 355.5, -32.5};
-    static constexpr double Q[6] = {162.421875, -1949.0625, 3248.4375, -1732.5, 371.25, -33.0};
-};
-
-template <> struct JFrac<8> {
-    static constexpr int NP = 7, NQ = 8;
-    static constexpr double P[7] = {-64803.8671875, 219904.453125, -203322.65625, 77869.6875, -14375.625, 1335.75, -59.5};
-    static constexpr double Q[8] = {7918.06640625, -126689.0625, 295607.8125, -236486.25, 84459.375, -15015.0, 1365.0, -60.0};
+template <> struct GHFrac<6> {
+    static constexpr double Z[6] = {9.87470140684811870e-02, 8.98302834569617681e-01, 2.55258980266817126e+00,
+                                    5.19615253005446576e+00, 9.12424803753117963e+00, 1.51299597811080861e+01};
+    static constexpr double C[6] = {6.43328723025660021e-01, 2.93934096090659958e-01, 5.82333758247283034e-02,
+                                    4.40676137506639757e-03, 9.67436984518125592e-05, 2.99985433527433577e-07};
 };
 
-template <int N>
-VAMP_DEV void poly_monic(const double (&a)[N], double zr, double zi, double r, double s, double& re, double& im) {
-    if constexpr (N == 1) {
-        re = zr + a[0];
-        im = zi;
-    } else {
-        double u2 = 1.0, u1 = a[N - 1] + r;
-#pragma unroll
-        for (int j = N - 2; j >= 1; --j) {
-            const double t = fma(r, u1, fma(-s, u2, a[j]));
-            u2 = u1;
-            u1 = t;
-        }
-        re = fma(zr, u1, fma(-s, u2, a[0]));
-        im = zi * u1;
-    }
+// An opaque zero: the constants of a branch are read through `table + opaque_zero()`, which keeps
+// their scalar loads INSIDE the branch that uses them.  Left to itself the compiler hoists every
+// fp64 literal of every branch in front of the pixel loop, runs out of SGPRs (VOP3 takes no 64-bit
+// immediate on gfx950) and parks the overflow in VGPRs: 179 VGPRs, 2 waves per SIMD.
+VAMP_DEV int opaque_zero() {
+#if defined(__HIPCC__)
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+#else
+    return 0;
+#endif
 }
 
-// plain complex Horner (4 FMAs per coefficient): used for the 6-level fraction, where the
-// 2-FMA recurrence loses a digit to cancellation near the real axis (3.5e-14 vs 4e-15)
-template <int N>
-VAMP_DEV void poly_monic_horner(const double (&a)[N], double zr, double zi, double& re, double& im) {
-    double pr = zr + a[N - 1], pi = zi;
-#pragma unroll
-    for (int j = N - 2; j >= 0; --j) {
-        const double t = fma(pr, zr, fma(-pi, zi, a[j]));
-        pi = fma(pr, zi, pi * zr);
-        pr = t;
-    }
-    re = pr;
-    im = pi;
-}
-
-// numerator and denominator of sqrt(pi) Re w = num/den; r2 = x^2 + y^2 is passed in (the caller
-// has it for the tier test)
+// num/den = sqrt(pi) Re w (num carries the factor y).  r2 = x^2 + y^2, y2 = y^2.
+//   D_j = (Re z^2 - zeta_j)^2 + (Im z^2)^2,  N_j = c_j r2 + c_j zeta_j
 template <int M>
 VAMP_DEV void voigt_jfrac_nd(double x, double y, double r2, double& num, double& den) {
-    using C = JFrac<M>;
-    const double zr = fma(x, x, -(y * y));   // zeta = z^2
-    const double zi = x * (y + y);           // y + y is per line: hoisted out of the pixel loop
-    double pr, pi, qr, qi;
-    if constexpr (M >= 6) {
-        poly_monic_horner<C::NP>(C::P, zr, zi, pr, pi);
-        poly_monic_horner<C::NQ>(C::Q, zr, zi, qr, qi);
-    } else {
-        const double r = zr + zr;
-        const double s = r2 * r2;            // |zeta|^2
-        poly_monic<C::NP>(C::P, zr, zi, r, s, pr, pi);
-        poly_monic<C::NQ>(C::Q, zr, zi, r, s, qr, qi);
+    using G = GHFrac<M>;
+    // the two hot branches (2 and 3 levels: 80 % of the evaluations of a long region) keep their
+    // ten constants in registers; the deeper ones reload theirs on entry
+    const double* Zt = G::Z + (M >= 4 ? opaque_zero() : 0);
+    const double* Ct = G::C + (M >= 4 ? opaque_zero() : 0);
+    const double y2 = y * y;
+    const double zr = fma(x, x, -y2);        // Re z^2
+    const double zi2 = (4.0 * y2) * (zr + y2);   // (Im z^2)^2 = 4 x^2 y^2
+    double t = zr - Zt[0];
+    double N = Ct[0] * (r2 + Zt[0]);
+    double D = fma(t, t, zi2);
+#pragma unroll
+    for (int j = 1; j < M; ++j) {
+        t = zr - Zt[j];
+        const double Nj = Ct[j] * (r2 + Zt[j]);
+        const double Dj = fma(t, t, zi2);
+        N = fma(N, Dj, Nj * D);
+        D = D * Dj;
     }
-    const double ar = fma(x, pr, -(y * pi));
-    const double ai = fma(x, pi, y * pr);
-    num = fma(ar, qi, -(ai * qr));
-    den = fma(qr, qr, qi * qi);
+    num = y * N;
+    den = D;
 }
 
 template <int M>
