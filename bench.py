@@ -274,7 +274,7 @@ def main():
             "acceptance_fraction": acc_frac,
             "finite_lnprob_fraction": finite_frac,
         }
-        if not args.no_cpu_baseline and args.dtype == "f64":
+        if not args.no_cpu_baseline and args.dtype == "f64" and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)
 
