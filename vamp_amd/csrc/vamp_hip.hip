@@ -80,14 +80,18 @@ struct LineRec {           // per (walker, component), lives in LDS
 // wave); KCAP bounds the lines per walker and so the LDS footprint.  <64,16> is the headline shape
 // (thousands of pixels per region); <16,8> serves the 9..478-pixel regions of real spectra, where
 // one walker cannot fill a wave and the per-walker fixed work (staging, draws, reduction) dominates.
-template <int LPW_, int KCAP_, bool TAIL_>
+template <int LPW_, int KCAP_, bool TAIL_, int WPB_>
 struct Pack {
     static constexpr int LPW = LPW_, KCAP = KCAP_, SUBS = 64 / LPW_;
     static constexpr bool TAIL = TAIL_;     // false: every region is a whole number of full tiles
+    static constexpr int WPB = WPB_;        // wavefronts per workgroup
+    static constexpr int THREADS = 64 * WPB_;
+    static constexpr int WALKERS_PER_BLOCK = WPB_ * SUBS;
 };
-using PackWide = Pack<64, KMAX, true>;
-using PackWideFull = Pack<64, KMAX, false>;   // the headline shape: no tail code, fewer registers
-using PackSmall = Pack<16, 8, true>;
+using PackWide = Pack<64, KMAX, true, WAVES_PER_BLOCK>;
+using PackWideFull = Pack<64, KMAX, false, WAVES_PER_BLOCK>;   // the headline shape: no tail code
+// 8 walkers x 3.7 KB of LDS per 128-thread workgroup: 5 workgroups (10 waves) per CU
+using PackSmall = Pack<16, 8, true, 2>;
 
 template <int KCAP>
 struct WalkerLds {
@@ -452,13 +456,13 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::
 // kernels
 // ---------------------------------------------------------------------------------------
 template <bool F32, int MODE, class PK>
-__global__ __launch_bounds__(BLOCK) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
+__global__ __launch_bounds__(PK::THREADS) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
                                                   long long W, const double* __restrict__ theta,
                                                   double* __restrict__ lnprob, double* __restrict__ chi2) {
-    __shared__ WalkerLds<PK::KCAP> lds[WAVES_PER_BLOCK * PK::SUBS];
+    __shared__ WalkerLds<PK::KCAP> lds[PK::WALKERS_PER_BLOCK];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
-    const long long w = ((long long)blockIdx.x * WAVES_PER_BLOCK + wave) * PK::SUBS + sub;
+    const long long w = ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS + sub;
     if (w >= W) return;
     const RegionDev R = regions[region];
     WalkerLds<PK::KCAP>& L = lds[wave * PK::SUBS + sub];
@@ -598,15 +602,18 @@ struct SamplerDev {
 // One half-step of the stretch move, one wavefront per active walker.
 //   EXT = draws supplied by the host (deterministic-parity hook); else Philox in-kernel.
 template <bool F32, bool EXT, int MODE, class PK>
-__global__ __launch_bounds__(BLOCK) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
+__global__ __launch_bounds__(PK::THREADS) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
                                                      long long ext_n, const int* __restrict__ ext_active,
                                                      const int* __restrict__ ext_partner, const double* __restrict__ ext_z,
                                                      const double* __restrict__ ext_logu) {
-    __shared__ WalkerLds<PK::KCAP> lds[WAVES_PER_BLOCK * PK::SUBS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ WalkerLds<PK::KCAP> lds[PK::WALKERS_PER_BLOCK];
+    const int lane = threadIdx.x & 63;
+    // the wave index is the same in every lane: say so, and the draws below (Philox rounds, the
+    // split bijection -- all integer) run on the scalar unit when a wave serves one walker
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
     const long long halfW = S.W >> 1;
-    const long long slot0 = ((long long)blockIdx.x * WAVES_PER_BLOCK + wave) * PK::SUBS;   // first walker of this wave
+    const long long slot0 = ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS;   // first walker of this wave
     long long slot = slot0 + sub;
     int region;
     long long ws, wc;            // local walker ids (within the region) of mover and partner
@@ -814,8 +821,9 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     // below that a wave per walker has the shorter critical path)
     const bool small = c->packed && !ext && (c->W / 2) % subs == 0 && (c->split_block / 2) % subs == 0 &&
                        (c->packing == 16 || n >= PACK_MIN_WALKERS);
-    const long long per_block = (long long)WAVES_PER_BLOCK * (small ? subs : 1);
+    const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : PackWide::WALKERS_PER_BLOCK;
     const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
+    const unsigned threads = small ? PackSmall::THREADS : PackWide::THREADS;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev.size()) {
@@ -838,19 +846,19 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     const PixPtrs px = c->pix();
     if (ext) {
         if (c->f32)
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<true, true, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<true, true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
                                                       half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d));
         else
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<false, true, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<false, true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
                                                       half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d));
     } else {
         const int* ni = nullptr;
         const double* nd = nullptr;
         if (c->f32)
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<true, false, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<true, false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
                                                       half, 0, 0ll, ni, ni, nd, nd));
         else
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<false, false, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<false, false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
                                                       half, 0, 0ll, ni, ni, nd, nd));
     }
     HIP_TRY(hipGetLastError());
@@ -1074,13 +1082,14 @@ int vamp_lnprob(vamp_ctx* c, int region, int64_t W, const double* theta, double*
     double *th_d = c->sc_th, *lp_d = c->sc_lp, *ch_d = chi2 ? c->sc_chi : nullptr;
     HIP_TRY(hipMemcpyAsync(th_d, theta, nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const bool small = c->packed && (c->packing == 16 || W >= PACK_MIN_WALKERS);
-    const long long per_block = (long long)WAVES_PER_BLOCK * (small ? PackSmall::SUBS : 1);
+    const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : PackWide::WALKERS_PER_BLOCK;
     const unsigned grid = (unsigned)((W + per_block - 1) / per_block);
+    const unsigned threads = small ? PackSmall::THREADS : PackWide::THREADS;
     if (c->f32)
-        VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region,
+        VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, region,
                                                   c->pix(), (long long)W, th_d, lp_d, ch_d));
     else
-        VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, region,
+        VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, region,
                                                   c->pix(), (long long)W, th_d, lp_d, ch_d));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(lnprob, lp_d, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1196,14 +1205,15 @@ int vamp_sampler_init(vamp_ctx* c, int64_t W, const double* theta0, uint64_t see
     for (int r = 0; r < c->n_regions; ++r) {
         const RegionDev& R = c->regions_h[r];
         const bool small = c->packed && (c->packing == 16 || W >= PACK_MIN_WALKERS);
-        const long long per_block = (long long)WAVES_PER_BLOCK * (small ? PackSmall::SUBS : 1);
+        const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : PackWide::WALKERS_PER_BLOCK;
         const unsigned grid = (unsigned)((W + per_block - 1) / per_block);
+        const unsigned threads = small ? PackSmall::THREADS : PackWide::THREADS;
         double* nochi = nullptr;
         if (c->f32)
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, r,
                                                       c->pix(), (long long)W, c->X_d + R.theta_off, c->lnp_d + R.walker_off, nochi));
         else
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(BLOCK), 0, c->stream, c->regions_d, r,
+            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, r,
                                                       c->pix(), (long long)W, c->X_d + R.theta_off, c->lnp_d + R.walker_off, nochi));
         HIP_TRY(hipGetLastError());
     }
