@@ -7,11 +7,12 @@
 // wave-uniform and each wave normally executes one branch.
 //
 //   |z|^2 >= 1e8          1-level J-fraction, overflow-safe closed form
-//   |z|^2 >= 1e4          2-level J-fraction      K_m(zeta) = P_{m-1}(zeta)/Q_m(zeta), zeta = z^2
-//   |z|^2 >= 625          3-level                 w(z) = (i z / sqrt(pi)) K(zeta)
-//   |z|^2 >= 196          4-level                 (even contraction of Laplace's continued
-//   |z|^2 >= 64           6-level                  fraction; = Gauss-Hermite quadrature of the
-//                                                  Cauchy integral, so Re w keeps its factor y)
+//   |z|^2 >= 1e4          2-level J-fraction      w(z) = (i z / sqrt(pi)) K_m(zeta), zeta = z^2: even
+//   |z|^2 >= 625          3-level                 contraction of Laplace's continued fraction = m-point
+//   |z|^2 >= 196          4-level                 Gauss-Hermite quadrature of the Cauchy integral, so
+//   |z|^2 >= 64           6-level                 Re w keeps its factor y.  Evaluated through the partial
+//                                                 fractions of K_m: m positive real terms over one
+//                                                 denominator (see GHFrac below)
 //   otherwise             midpoint trapezoid rule, step h = 1/2, nodes centred on x:
 //        H = A(y) e^{-x^2} cos(2xy) + (h y/pi) sum_n e^{-(x-u_n)^2} / (u_n^2 + y^2),
 //        u_n = (n+1/2) h, A(y) = 2 e^{y^2} / (1 + e^{2 pi y/h})        (pole correction)
@@ -22,7 +23,7 @@
 //   For y < 1e-9 the truncated fractions miss the (then dominant) e^{-x^2} term; it is added.
 //
 // Measured against 60+-digit mpmath over |z| in [1e-3, 300], y in [1e-300, 300]: max relative
-// error 6e-15 (scipy.special.wofz itself: 2e-14).  Constants: tools/gen_voigt_tables.py.
+// error 3e-15 in the fraction branches, 6e-15 overall (scipy.special.wofz itself: 2e-14).  Constants: tools/gen_voigt_tables.py.
 //
 // fp32 variant: Humlicek's W4 (JQSRT 27 (1982) 437), the four-region rational approximation.
 #pragma once
@@ -328,16 +329,15 @@ VAMP_DEV double voigt_Hs(double x, double y, const double* dtab, double pole, do
         return x * y;             // 6: no Voigt arithmetic at all (loop + staging overhead)
     }
 #endif
+    if (r2 < R2_CORE) return voigt_core(x, y, dtab, pole, hy);     // (NaN compares false: no table lookup)
     double H;
     if (r2 >= R2_M3) {
         if (r2 >= R2_M1) H = voigt_far(x, y, r2);
         else if (r2 >= R2_M2) H = voigt_jfrac<2>(x, y, r2);
         else H = voigt_jfrac<3>(x, y, r2);
-    } else if (r2 >= R2_CORE) {
+    } else {
         if (r2 >= R2_M4) H = voigt_jfrac<4>(x, y, r2);
         else H = voigt_jfrac<6>(x, y, r2);
-    } else {
-        return voigt_core(x, y, dtab, pole, hy);
     }
     if (y < Y_TINY) H += SQRT_PI * exp_neg_sq(x);
     return H;
