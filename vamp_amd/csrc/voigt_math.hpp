@@ -170,10 +170,12 @@ template <int M> struct GHFrac;
 template <> struct GHFrac<2> {
     static constexpr double Z[2] = {2.75255128608410948e-01, 2.72474487139158894e+00};
     static constexpr double C[2] = {9.08248290463863017e-01, 9.17517095361369828e-02};
+    static constexpr double CZ[2] = {C[0] * Z[0], C[1] * Z[1]};
 };
 template <> struct GHFrac<3> {
     static constexpr double Z[3] = {1.90163509193488123e-01, 1.78449274854325157e+00, 5.52534374226326008e+00};
     static constexpr double C[3] = {8.17656939112058501e-01, 1.77231492083829045e-01, 5.11156880411249310e-03};
+    static constexpr double CZ[3] = {C[0] * Z[0], C[1] * Z[1], C[2] * Z[2]};
 };
 template <> struct GHFrac<4> {
     static constexpr double Z[4] = {1.45303521503317101e-01, 1.33909728812636142e+00, 3.92696350135828709e+00,
@@ -214,13 +216,18 @@ VAMP_DEV void voigt_jfrac_nd(double x, double y, double r2, double& num, double&
     const double y2 = y * y;
     const double zr = fma(x, x, -y2);        // Re z^2
     const double zi2 = (4.0 * y2) * (zr + y2);   // (Im z^2)^2 = 4 x^2 y^2
+    // N_j: one FMA with a third literal per term in the hot branches, add + multiply in the deep ones
+    auto Nterm = [&](int j) {
+        if constexpr (M < 4) return fma(G::C[j], r2, G::CZ[j]);
+        else return Ct[j] * (r2 + Zt[j]);
+    };
     double t = zr - Zt[0];
-    double N = Ct[0] * (r2 + Zt[0]);
+    double N = Nterm(0);
     double D = fma(t, t, zi2);
 #pragma unroll
     for (int j = 1; j < M; ++j) {
         t = zr - Zt[j];
-        const double Nj = Ct[j] * (r2 + Zt[j]);
+        const double Nj = Nterm(j);
         const double Dj = fma(t, t, zi2);
         N = fma(N, Dj, Nj * D);
         D = D * Dj;
