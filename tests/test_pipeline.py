@@ -193,3 +193,25 @@ def test_config3_all_regions_batched():
             chain, lchain, na = vo.run_sampler(fn, theta0[r], fn(theta0[r]), 4, seed=99, block=W, region=r, walker_off=r * W)
             assert np.allclose(X[r], chain[-1], rtol=1e-9, atol=1e-11), r
             assert np.array_equal(nacc[r], na), r
+
+
+@pytest.mark.gpu
+def test_fit_spectrum_batched_matches_sequential_shape(tmp_path):
+    """vamp_amd.batched: the BIC ladders of all regions of a spectrum advance together (one ragged
+    launch per half-step).  Same outputs as the sequential path; every region ends with a fit that
+    beats the flat continuum, and the number of lines per region is small for these simple regions."""
+    from vamp_amd.vpspectrum import VPspectrum
+    g = load_golden("simba_spectra.npz")
+    sp = VPspectrum(1036.3367, voigt=False, nwalkers=32, iterations=300, thin=5, burn=100, seed=11, verbose=False)
+    sp.set_arrays(g["CII1036_wavelength"], g["CII1036_flux"], g["CII1036_noise"])
+    params = sp.fit_spectrum(batched=True)
+    assert sp.region_pixels == [list(r) for r in g["CII1036_region_pixels"]]
+    n_lines = [r.n for r in sp.regions]
+    assert all(1 <= n <= 5 for n in n_lines), n_lines
+    assert params["b"].size == sum(n_lines) == params["N"].size == params["centers"].size
+    for r in sp.regions:
+        flat = r.fit.ReducedChisquared(r.flux_array, np.ones_like(r.flux_array), r.noise_array, r.freedom)
+        assert r.best_chi_squared < 0.2 * flat
+        assert len(r.fit.bic_array) == 3 and np.all(np.isfinite(r.fit.bic_array))
+        assert r.fit.total.value.shape == r.flux_array.shape
+    assert np.all(sp.flux_model["total"] <= 1.0 + 1e-12)

@@ -18,7 +18,7 @@ def fit_one(path, args, device=0):
     spec = VPspectrum(args.line, path, args.output_folder, voigt=args.voigt, chi_limit=1.5, mcmc_cov=False,
                       get_mcmc_err=True, convergence_attempts=args.conv_attempts, nwalkers=args.walkers,
                       iterations=args.iterations, thin=args.thin, burn=args.burn, seed=args.seed)
-    return spec.fit_spectrum()
+    return spec.fit_spectrum(batched=args.batched)
 
 
 def _worker(rank, files, args):
@@ -40,6 +40,8 @@ def main(argv=None):
     p.add_argument("--burn", type=int, default=300)
     p.add_argument("--thin", type=int, default=15)
     p.add_argument("--seed", type=int, default=None)
+    p.add_argument("--batched", action="store_true",
+                   help="fit all regions of a spectrum together (one kernel launch per half-step for the whole spectrum)")
     args = p.parse_args(argv)
     if args.output_folder is not None:
         os.makedirs(args.output_folder, exist_ok=True)

@@ -124,6 +124,8 @@ class VPfit():
         self._seed = np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0] if seed is not None \
             else np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0]
         self._ctx = None
+        self._region = 0          # index of this fit's region inside the context (batched fits share one)
+        self._shared_ctx = False
 
     # ---- statics (vpfits.py:43-131), host numpy as in the reference -------------------------
     @staticmethod
@@ -185,10 +187,11 @@ class VPfit():
         self._mode = hb.MODE_VOIGT4 if voigt else hb.MODE_GAUSS3
         self._q = 4 if voigt else 3
         self._ndim = self._q * self._n + (1 if self._sample_sd else 0)
-        noise = np.ones_like(flux) if self._sample_sd else self.noise
-        if self._ctx is None:
-            self._ctx = hb.HipContext(device=self.device, dtype=self.dtype)
-        self._ctx.set_regions(self._x, flux, noise, self._n, mode=self._mode, sample_sd=self._sample_sd)
+        if not self._shared_ctx:      # a batched fit's region is uploaded by vamp_amd.batched
+            noise = np.ones_like(flux) if self._sample_sd else self.noise
+            if self._ctx is None:
+                self._ctx = hb.HipContext(device=self.device, dtype=self.dtype)
+            self._ctx.set_regions(self._x, flux, noise, self._n, mode=self._mode, sample_sd=self._sample_sd)
 
         # parameter names and unit scales (device units -> caller units)
         names, keys, scale, shift = [], [], [], []
@@ -258,14 +261,14 @@ class VPfit():
                 self._sd_node.value = float(v)
             else:
                 self.estimated_variables[k][key].value = float(v)
-        tau, flux = self._ctx.model(theta_dev)
+        tau, flux = self._ctx.model(theta_dev, region=self._region)
         for k in range(self._n):
             self.estimated_profiles[k].value = tau[k].copy()
         self.total.value = flux
 
     def _loglike(self, theta_dev):
         """log-likelihood of the observed flux (device chi^2 / SSR, host epilogue)"""
-        lnp, s = self._ctx.lnprob(theta_dev, return_chi2=True)
+        lnp, s = self._ctx.lnprob(theta_dev, region=self._region, return_chi2=True)
         th = np.atleast_2d(theta_dev)
         if self._sample_sd:
             t = 1.0 / th[:, -1] ** 2
@@ -282,10 +285,10 @@ class VPfit():
 
     def _run_map(self, iterlim, tol, mp):
         from scipy.optimize import fmin
-        ctx = self._ctx
+        ctx, reg = self._ctx, self._region
 
         def neg(th):
-            v = ctx.lnprob(th)[0]
+            v = ctx.lnprob(th, region=reg)[0]
             return -v if np.isfinite(v) else 1e300
 
         start = self._theta_dev
@@ -296,7 +299,7 @@ class VPfit():
         if neg(best) > neg(start):
             best = start
         self._set_values(best)
-        mp.logp_at_max = float(ctx.lnprob(best)[0])
+        mp.logp_at_max = float(ctx.lnprob(best, region=reg)[0])
         mp.lnL = float(self._loglike(best)[0])
         k, n = self._ndim, self._flux.size
         mp.len, mp.data_len = k, n
@@ -318,28 +321,38 @@ class VPfit():
         self.fit_time = str(datetime.datetime.now() - starttime)
         print("\nTook:", self.fit_time, " to finish.")
 
-    def _run_sampler(self, iterations, burn, thin):
+    def _initial_walkers(self):
+        """[W, D] start of the ensemble: a ball around the current point (the MAP, when
+        map_estimate ran first) widened with prior draws so that a poor start cannot trap it."""
         W = int(self.nwalkers)
         W = max(W, 2 * self._ndim + 2)
         W += W % 2
         rng = np.random.default_rng((int(self._seed) >> 16) & 0xFFFFFFFF)
-        # walkers: a tight ball around the current point (the MAP, when map_estimate ran first),
-        # widened with prior draws so that a poor start cannot trap the whole ensemble
         centre = self._theta_dev
         span = np.abs(self._draw_prior(rng, W) - centre)
         X0 = centre + 1e-2 * span * rng.standard_normal((W, self._ndim))
         prior = self._draw_prior(rng, W)
-        lnp = self._ctx.lnprob(X0)
+        lnp = self._ctx.lnprob(X0, region=self._region)
         bad = ~np.isfinite(lnp)
         X0[bad] = prior[bad]
         X0[0] = centre
+        return X0
+
+    def _run_sampler(self, iterations, burn, thin):
+        X0 = self._initial_walkers()
+        W = X0.shape[0]
         self._ctx.sampler_init(X0, seed=int(self._seed), a=2.0, split_block=hb.default_split_block(W))
         if burn > 0:
             self._ctx.run(burn, store_chain=False)
         thin = max(1, thin)
         keep = max(thin, iterations - burn)            # always keep at least one sample
         res = self._ctx.run(keep, thin=thin)
-        chain, lnpc = res["chain"], res["lnprob"]          # [n_keep, W, D], [n_keep, W]
+        self._ingest_chain(res["chain"], res["lnprob"], res["n_accept"], burn + keep, keep, res["seconds"])
+
+    def _ingest_chain(self, chain, lnpc, n_accept, steps, keep, seconds):
+        """chain [n_keep, W, D] / lnprob [n_keep, W] of THIS fit's region -> traces, acceptance,
+        DIC / BPIC, node values."""
+        W = chain.shape[1]
         self._chain_dev, self._lnp_chain = chain, lnpc
         flat = self._to_caller(chain.reshape(-1, self._ndim))
         mc_ = self.mcmc
@@ -347,9 +360,8 @@ class VPfit():
         if self._voigt:      # the reference's callers ask for est_sigma_k in Voigt mode too (vpspectrum.py:400)
             for k in range(self._n):
                 mc_._traces["est_sigma_%d" % k] = self.GaussianWidth(mc_._traces["est_G_%d" % k])
-        steps = burn + keep
-        mc_.acceptance_fraction = float(res["n_accept"].mean()) / max(1, steps)
-        mc_.walker_steps_per_second = W * keep / res["seconds"] if res["seconds"] > 0 else float("nan")
+        mc_.acceptance_fraction = float(np.mean(n_accept)) / max(1, steps)
+        mc_.walker_steps_per_second = W * keep / seconds if seconds > 0 else float("nan")
         # information criteria from the chain (every kept sample scored on the device)
         ll = self._loglike(chain.reshape(-1, self._ndim))
         dev_mean = float(np.mean(-2.0 * ll[np.isfinite(ll)]))

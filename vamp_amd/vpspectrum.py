@@ -213,12 +213,16 @@ class VPspectrum():
         if self.verbose:
             print("Split one {}-component region into {} regions.".format(region.n, len(self.region_pixels)))
 
-    def fit_spectrum(self):
+    def fit_spectrum(self, batched=False):
         """Detect regions, fit each (retrying up to ``convergence_attempts`` times, keeping the best
         reduced chi^2), harvest N, b, EW, centres and their errors (vpspectrum.py:243-442).
-        Returns the ``params`` dict."""
+        Returns the ``params`` dict.  ``batched=True`` runs the BIC ladders of all regions together
+        (one kernel launch per half-step for the whole spectrum, vamp_amd/batched.py; one attempt
+        per region)."""
         self.compute_detection_regions(min_region_width=2)
         self.split_difficult_region()
+        if batched:
+            return self._fit_spectrum_batched()
         empty = lambda: np.array([])
         self.params = {k: empty() for k in ('b', 'b_std', 'N', 'N_std', 'EW', 'centers', 'region_numbers')}
         nreg = len(self.region_pixels)
@@ -260,6 +264,33 @@ class VPspectrum():
             region.n = len(region.fit.estimated_profiles)
             self._harvest(j, start, end, waves, region)
             self.regions.append(region)
+        if self.out_folder is not None:
+            name = os.path.basename(self.spectrum_file or "spectrum")
+            name = name[:name.find('.')] if '.' in name else name
+            self.output_filename = os.path.join(self.out_folder, name) + ('_voigt_' if self.voigt else '_gauss_')
+            self.plot_spectrum()
+            self.write_file()
+        return self.params
+
+    def _fit_spectrum_batched(self):
+        from .batched import BatchedRegionLadder
+        empty = lambda: np.array([])
+        self.params = {k: empty() for k in ('b', 'b_std', 'N', 'N_std', 'EW', 'centers', 'region_numbers')}
+        nreg = len(self.region_pixels)
+        self.flux_model = {'total': np.ones(len(self.flux_array)), 'chi_squared': np.zeros(nreg),
+                           'region_pixels': self.region_pixels, 'amplitude': empty(), 'sigmas': empty(),
+                           'centers': empty(), 'region_numbers': empty(), 'EW': np.zeros(nreg), 'std_a': empty(),
+                           'std_s': empty(), 'std_c': empty(), 'cov_as': empty(), 'difficult_fit': self.difficult_fit}
+        self.regions = [self._region(s, e) for s, e in self.region_pixels]
+        for r in self.regions:
+            r.n = min(r.n, 8)           # ragged batches keep to 8 lines per region (four walkers per wavefront)
+        BatchedRegionLadder(self.regions, nwalkers=self.nwalkers or 64, iterations=self.iterations, thin=self.thin,
+                            burn=self.burn, seed=self.seed or 0, verbose=self.verbose).run()
+        for j, ((start, end), region) in enumerate(zip(self.region_pixels, self.regions)):
+            region.set_freedom()
+            region.best_chi_squared = region.fit.ReducedChisquared(region.flux_array, region.fit.total.value,
+                                                                   region.noise_array, region.freedom)
+            self._harvest(j, start, end, np.flip(self.wavelength_array[start:end], 0), region)
         if self.out_folder is not None:
             name = os.path.basename(self.spectrum_file or "spectrum")
             name = name[:name.find('.')] if '.' in name else name
