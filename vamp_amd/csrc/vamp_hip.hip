@@ -93,12 +93,20 @@ using PackWideFull = Pack<64, KMAX, false, WAVES_PER_BLOCK>;   // the headline s
 // 8 walkers x 3.7 KB of LDS per 128-thread workgroup: 5 workgroups (10 waves) per CU
 using PackSmall = Pack<16, 8, true, 2>;
 
+constexpr int FF_NODES = 16;          // Chebyshev nodes of the far-field interpolant of one tile
+#ifndef VAMP_FF_DIST
+#define VAMP_FF_DIST 4.0
+#endif
+constexpr double FF_DIST = VAMP_FF_DIST;   // a line is "far" from a tile when it lies >= FF_DIST half-widths beyond its edge
+
 template <int KCAP>
 struct WalkerLds {
     double theta[4 * KCAP + 4];
     LineRec line[KCAP];
     double dtab[KCAP][vamp::DTAB_N];
     float linef[KCAP][4];  // fp32 path: c, s, y, amp
+    double ffval[FF_NODES]; // far-field optical depth at the tile's Chebyshev nodes, then its coefficients
+    int farlist[KCAP];      // lines treated through the far field in the current tile
 };
 using WaveLds = WalkerLds<KMAX>;      // the one-walker-per-wavefront kernels (k_model, k_line_records)
 
@@ -330,12 +338,204 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<
     }
 }
 
+// ---- far-field aggregation ----------------------------------------------------------------
+// Seen from a tile of 256 consecutive pixels, a line whose centre lies >= FF_DIST half-widths
+// beyond the tile's edge contributes an optical depth that is analytic across the tile with its
+// nearest singularity (the line centre) that far away: a degree-15 Chebyshev interpolant
+// reproduces it to 4e-15 relative (singularity at (FF_DIST + 1) half-widths from the tile centre:
+// Bernstein ellipse parameter 5 + sqrt(24) = 9.9 for FF_DIST = 4, and 9.9^-16 = 1.2e-16).  Polynomials add, so ALL far lines of the tile share one interpolant:
+//   1. the (node, far line) pairs -- 16 nodes x up to 16 lines -- are spread over the 64 lanes
+//      (lane = 16 * (line slot) + node) and evaluated with the same Voigt code, 4 lines per pass;
+//   2. node values are summed over lines (two xor shuffles), turned into Chebyshev coefficients
+//      by a 16 x 16 DCT held in LDS (one row per lane), and
+//   3. every pixel of the tile evaluates ONE Clenshaw recurrence (32 instructions) instead of
+//      ~27 instructions per far line.
+// On the headline workload ~90 % of the (pixel, line) evaluations are far: 64 wave-evaluations
+// per tile shrink to ~6 direct ones + ~4 at the nodes.
+constexpr int FF_TABLE = FF_NODES * FF_NODES + FF_NODES;   // DCT matrix [j][m] followed by the node abscissae
+
+// cos(pi k / 32) for any integer k, through an exact integer reduction to k in [0, 16]
+__device__ __forceinline__ double ff_cos_pi32(int k) {
+    k &= 63;
+    if (k > 32) k = 64 - k;
+    double sgn = 1.0;
+    if (k > 16) { k = 32 - k; sgn = -1.0; }
+    return sgn * vamp::cos_small((double)k * 9.81747704246810387019e-02);     // pi / 32
+}
+
+// every thread of the workgroup fills its share; call before any thread can leave the kernel
+__device__ __forceinline__ void ff_fill_table(double* dct) {
+    for (int e = threadIdx.x; e < FF_TABLE; e += blockDim.x) {
+        if (e < FF_NODES * FF_NODES) {
+            const int j = e / FF_NODES, m = e % FF_NODES;            // (2/16) cos(m pi (j + 1/2) / 16)
+            dct[e] = (2.0 / FF_NODES) * ff_cos_pi32(m * (2 * j + 1));
+        } else {
+            dct[e] = ff_cos_pi32(2 * (e - FF_NODES * FF_NODES) + 1);  // cos(pi (j + 1/2) / 16)
+        }
+    }
+    __syncthreads();
+}
+
+// sqrt(pi) H at one point per slot for FOUR different lines per lane (x[t], y[t]); every point has
+// |z|^2 >= 64.  One branch for the wavefront, the deepest any of its 256 points needs; two
+// reciprocals for four evaluations.
+template <int M>
+__device__ __forceinline__ void ff_frac4(const double (&X)[4], const double (&y)[4], const double (&r2)[4], double (&H)[4]) {
+    double n[4], d[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vamp::voigt_jfrac_nd<M>(X[t], y[t], r2[t], n[t], d[t]);
+    const double ra = vamp::rcp_nr(d[0] * d[1]), rb = vamp::rcp_nr(d[2] * d[3]);
+    H[0] = n[0] * (ra * d[1]);
+    H[1] = n[1] * (ra * d[0]);
+    H[2] = n[2] * (rb * d[3]);
+    H[3] = n[3] * (rb * d[2]);
+}
+
+__device__ __forceinline__ void ff_eval4(const double (&Xin)[4], const double (&y)[4], double (&H)[4]) {
+    double X[4], r2[4];
+    double lo, hi, ymin;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        X[t] = fmin(Xin[t], vamp::X_FAR);       // lanes hold different lines: always guard the promotion
+        r2[t] = fma(X[t], X[t], y[t] * y[t]);
+        lo = t ? fmin(lo, r2[t]) : r2[0];
+        hi = t ? fmax(hi, Xin[t]) : Xin[0];
+        ymin = t ? fmin(ymin, y[t]) : y[0];
+    }
+    if (__any(lo < vamp::R2_M3)) {
+        if (__any(lo < vamp::R2_M4)) ff_frac4<6>(X, y, r2, H);
+        else ff_frac4<4>(X, y, r2, H);
+    } else if (__any(lo < vamp::R2_M2)) {
+        ff_frac4<3>(X, y, r2, H);
+    } else {
+        ff_frac4<2>(X, y, r2, H);               // valid (more than accurate) beyond 1e8 too, up to X_FAR
+    }
+    if (__any(hi > vamp::X_FAR)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (Xin[t] > vamp::X_FAR) H[t] = vamp::voigt_far(Xin[t], y[t], fma(Xin[t], Xin[t], y[t] * y[t]));
+    }
+    if (__any(ymin < vamp::Y_TINY)) {           // the fractions miss e^{-x^2}; it matters for y < ~1e-11 near |z| = 8
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (y[t] < vamp::Y_TINY) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
+    }
+}
+
+template <int MODE, class PK>
+__device__ __forceinline__ void sweep_range_ff(const RegionDev& R, WalkerLds<PK::KCAP>& L, const double* __restrict__ dct,
+                                               const double* __restrict__ x, const double* __restrict__ f,
+                                               const double* __restrict__ wt, int lane, int base0, int base1, double& chi) {
+    constexpr int T = TPIX;
+    static_assert(PK::LPW == 64 && PK::KCAP <= 16, "far-field tiles: one walker per wavefront, <= 16 lines");
+    const int K = R.K;
+    const int node = lane & (FF_NODES - 1), grp = lane >> 4;
+    const double tnode = dct[FF_NODES * FF_NODES + node];          // cos(pi (node + 1/2) / 16)
+    // lane k < K classifies line k; w8 = half-width of |z|^2 < 64 around the line centre, in x units
+    const int kk = lane < K ? lane : 0;
+    const double my_c = L.line[kk].c;
+    const double my_w8 = sqrt(fmax(vamp::R2_CORE - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
+    for (int base = base0; base < base1; base += 64 * T) {
+        double xi[T], tau[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            xi[t] = x[base + 64 * t + lane];
+            tau[t] = 0.0;
+        }
+        // tile geometry (wave-uniform)
+        const double x_lo = x[base], x_hi = x[base + 64 * T - 1];
+        const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * (x_hi - x_lo);
+        // all lines classified at once: far = centre >= FF_DIST half-widths beyond the tile's edge and
+        // the whole tile outside |z|^2 < 64 of that line
+        const double dist = fabs(mid - my_c) - half;
+        const bool my_far = lane < K && dist >= FF_DIST * half && dist >= my_w8;
+        const unsigned long long farmask = __ballot(my_far);
+        const int nfar = __builtin_popcountll(farmask);
+        if (my_far) L.farlist[__builtin_popcountll(farmask & ((1ull << lane) - 1ull))] = lane;
+        for (int k = 0; k < K; ++k) {
+            if ((farmask >> k) & 1ull) continue;
+            const LineRec ln = L.line[k];
+            double X[T], H[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) X[t] = fabs(xi[t] - ln.c) * ln.s;
+            tile_voigt<T>(ln, L.dtab[k], X, H);
+#pragma unroll
+            for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
+        }
+        if (nfar > 0) {
+            __builtin_amdgcn_wave_barrier();
+            // 1. optical depth of the far lines at the tile's Chebyshev nodes: lane = (slot group, node),
+            //    four lines per lane (line q = 4 t + group of the compacted far list)
+            const double xnode = fma(half, tnode, mid);
+            double Xn[4], yn[4], an[4], Hn[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int q = 4 * t + grp;
+                const int k = L.farlist[q < nfar ? q : nfar - 1];
+                Xn[t] = fabs(xnode - L.line[k].c) * L.line[k].s;
+                yn[t] = L.line[k].y;
+                an[t] = q < nfar ? L.line[k].amp : 0.0;
+            }
+            ff_eval4(Xn, yn, Hn);
+            double fs = fma(an[0], Hn[0], an[1] * Hn[1]) + fma(an[2], Hn[2], an[3] * Hn[3]);
+            fs += __shfl_xor(fs, 16, 64);
+            fs += __shfl_xor(fs, 32, 64);
+            // 2. Chebyshev coefficients: c_m = (2/16) sum_j f_j cos(m pi (j + 1/2) / 16); lane m owns row m
+            if (lane < FF_NODES) L.ffval[lane] = fs;
+            __builtin_amdgcn_wave_barrier();
+            double cm = 0.0;
+#pragma unroll
+            for (int j = 0; j < FF_NODES; ++j) cm = fma(dct[j * FF_NODES + node], L.ffval[j], cm);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < FF_NODES) L.ffval[lane] = cm;
+            __builtin_amdgcn_wave_barrier();
+            // 3. Clenshaw at the tile's pixels
+            const double inv_half = 1.0 / half;
+            double tt2[T], b1[T], b2[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                tt2[t] = 2.0 * ((xi[t] - mid) * inv_half);
+                b1[t] = 0.0;
+                b2[t] = 0.0;
+            }
+#pragma unroll
+            for (int m = FF_NODES - 1; m >= 1; --m) {
+                const double c = L.ffval[m];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const double b0 = fma(tt2[t], b1[t], c - b2[t]);
+                    b2[t] = b1[t];
+                    b1[t] = b0;
+                }
+            }
+            const double c0h = 0.5 * L.ffval[0];
+#pragma unroll
+            for (int t = 0; t < T; ++t) tau[t] += fma(0.5 * tt2[t], b1[t], c0h - b2[t]);
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int i = base + 64 * t + lane;
+            const double m = vamp::exp_taylor(-tau[t]);
+            const double r = (f[i] - m) * wt[i];
+            chi = fma(r, r, chi);
+        }
+    }
+}
+
+#ifndef VAMP_FARFIELD
+#define VAMP_FARFIELD 1
+#endif
+
 template <int MODE, class PK = PackWide>
-__device__ __forceinline__ double sweep_f64(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x,
-                                            const double* __restrict__ f, const double* __restrict__ wt, int lane) {
+__device__ __forceinline__ double sweep_f64(const RegionDev& R, WalkerLds<PK::KCAP>& L, const double* __restrict__ dct,
+                                            const double* __restrict__ x, const double* __restrict__ f,
+                                            const double* __restrict__ wt, int lane) {
     double chi = 0.0;
     const int full = (R.P / (PK::LPW * TPIX)) * (PK::LPW * TPIX);
-    if (TPIX > 1) sweep_range<MODE, PK, TPIX>(R, L, x, f, wt, lane, 0, full, chi);
+    if constexpr (VAMP_FARFIELD && PK::SUBS == 1 && MODE != VAMP_GAUSS3 && TPIX == 4)
+        sweep_range_ff<MODE, PK>(R, L, dct, x, f, wt, lane, 0, full, chi);
+    else if (TPIX > 1) sweep_range<MODE, PK, TPIX>(R, L, x, f, wt, lane, 0, full, chi);
     if constexpr (PK::TAIL || TPIX == 1) sweep_range<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, chi);
     return wave_sum<PK::LPW>(chi);
 }
@@ -436,8 +636,8 @@ struct PixPtrs {
 // group.  Groups of one wave may leave early independently: everything below communicates only
 // inside a group (xor shuffles with offsets < LPW) or through __any, which ignores inactive lanes.
 template <bool F32, int MODE, class PK = PackWide>
-__device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::KCAP>& L, const PixPtrs& px, int lane,
-                                              double* chi_out) {
+__device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::KCAP>& L, const double* dct, const PixPtrs& px,
+                                              int lane, double* chi_out) {
     const double lp = stage_lines<MODE, PK>(R, L, lane, F32);
     if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
         if (chi_out) *chi_out = __builtin_nan("");
@@ -445,7 +645,7 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::
     }
     double ssum;
     if constexpr (F32) ssum = sweep_f32<MODE, PK>(R, L, px.xf + R.pix_off, px.ff + R.pix_off, px.wtf + R.pix_off, lane);
-    else ssum = sweep_f64<MODE, PK>(R, L, px.x + R.pix_off, px.f + R.pix_off, px.wt + R.pix_off, lane);
+    else ssum = sweep_f64<MODE, PK>(R, L, dct, px.x + R.pix_off, px.f + R.pix_off, px.wt + R.pix_off, lane);
     if (chi_out) *chi_out = ssum;
     double v = lp + loglike_from_sum(R, L, ssum);
     if (v != v) v = NEG_INF;                 // NaN -> -inf (emcee convention)
@@ -456,10 +656,12 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::
 // kernels
 // ---------------------------------------------------------------------------------------
 template <bool F32, int MODE, class PK>
-__global__ __launch_bounds__(PK::THREADS) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
+__global__ __launch_bounds__(PK::THREADS, 3) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
                                                   long long W, const double* __restrict__ theta,
                                                   double* __restrict__ lnprob, double* __restrict__ chi2) {
     __shared__ WalkerLds<PK::KCAP> lds[PK::WALKERS_PER_BLOCK];
+    __shared__ double dct[FF_TABLE];
+    ff_fill_table(dct);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
     const long long w = ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS + sub;
@@ -469,7 +671,7 @@ __global__ __launch_bounds__(PK::THREADS) void k_lnprob(const RegionDev* __restr
     for (int d = l; d < R.D; d += PK::LPW) L.theta[d] = theta[w * R.D + d];
     __builtin_amdgcn_wave_barrier();
     double chi;
-    const double v = wave_lnprob<F32, MODE, PK>(R, L, px, l, &chi);
+    const double v = wave_lnprob<F32, MODE, PK>(R, L, dct, px, l, &chi);
     if (l == 0) {
         lnprob[w] = v;
         if (chi2) chi2[w] = chi;
@@ -601,12 +803,19 @@ struct SamplerDev {
 
 // One half-step of the stretch move, one wavefront per active walker.
 //   EXT = draws supplied by the host (deterministic-parity hook); else Philox in-kernel.
+// 3 waves per SIMD (<= 168 VGPRs): the far-field path is latency-bound in places (LDS round trips);
+// measured 6.94 -> 6.49 ms against the allocator's unconstrained 182 VGPRs / 2 waves
+#ifndef VAMP_MIN_WAVES
+#define VAMP_MIN_WAVES 3
+#endif
 template <bool F32, bool EXT, int MODE, class PK>
-__global__ __launch_bounds__(PK::THREADS) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
+__global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
                                                      long long ext_n, const int* __restrict__ ext_active,
                                                      const int* __restrict__ ext_partner, const double* __restrict__ ext_z,
                                                      const double* __restrict__ ext_logu) {
     __shared__ WalkerLds<PK::KCAP> lds[PK::WALKERS_PER_BLOCK];
+    __shared__ double dct[FF_TABLE];
+    ff_fill_table(dct);
     const int lane = threadIdx.x & 63;
     // the wave index is the same in every lane: say so, and the draws below (Philox rounds, the
     // split bijection -- all integer) run on the scalar unit when a wave serves one walker
@@ -658,7 +867,7 @@ __global__ __launch_bounds__(PK::THREADS) void k_half_step(SamplerDev S, PixPtrs
         L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
     }
     __builtin_amdgcn_wave_barrier();
-    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, px, l, nullptr);
+    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, dct, px, l, nullptr);
     const long long wg = R.walker_off + ws;
     const double lnp_s = S.lnp[wg];
     const double diff = (double)(R.D - 1) * log(z) + lnp_q - lnp_s;
