@@ -41,6 +41,12 @@ constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
 constexpr int DMAX = 4 * KMAX + 1;
 constexpr long long PACK_MIN_WALKERS = 16384;   // automatic packing: walkers per launch needed to pay off
+// automatic splitting of a walker over the 4 waves of a workgroup: launches below this many walkers
+// (5 rounds of the chip's 3072 wavefront slots) whose regions give every wave >= 2 tiles
+#ifndef VAMP_SPLIT_MAX_WALKERS
+#define VAMP_SPLIT_MAX_WALKERS 16384
+#endif
+constexpr long long SPLIT_MAX_WALKERS = VAMP_SPLIT_MAX_WALKERS;
 
 constexpr double C_LIGHT = 2.98e8;     // physics.py:3 (the reference's value)
 constexpr double SIGMA0 = 0.0263;      // physics.py:4
@@ -80,16 +86,29 @@ struct LineRec {           // per (walker, component), lives in LDS
 // wave); KCAP bounds the lines per walker and so the LDS footprint.  <64,16> is the headline shape
 // (thousands of pixels per region); <16,8> serves the 9..478-pixel regions of real spectra, where
 // one walker cannot fill a wave and the per-walker fixed work (staging, draws, reduction) dominates.
-template <int LPW_, int KCAP_, bool TAIL_, int WPB_>
+//
+// SPLIT: the full tiles of a region are dealt round-robin into PARTS classes and chi^2 is summed
+// class by class (so the result does not depend on the packing).  SPLIT = false: one wavefront
+// sweeps all classes of its walker.  SPLIT = true: the workgroup serves ONE walker and wavefront j
+// sweeps class j -- four times as many, four times shorter wavefronts, for launches with too few
+// walkers to fill 256 CUs evenly (a shard of the headline ensemble on one of 8 GPUs is 4096
+// walkers per half-step = 1.3 wavefronts per SIMD slot; the drain at the end of a launch costs
+// about half a wavefront lifetime).  The group shares one set of line records and tables.
+constexpr int PARTS = 4;
+template <int LPW_, int KCAP_, bool TAIL_, int WPB_, bool SPLIT_ = false>
 struct Pack {
     static constexpr int LPW = LPW_, KCAP = KCAP_, SUBS = 64 / LPW_;
     static constexpr bool TAIL = TAIL_;     // false: every region is a whole number of full tiles
+    static constexpr bool SPLIT = SPLIT_;
     static constexpr int WPB = WPB_;        // wavefronts per workgroup
     static constexpr int THREADS = 64 * WPB_;
-    static constexpr int WALKERS_PER_BLOCK = WPB_ * SUBS;
+    static constexpr int WALKERS_PER_BLOCK = SPLIT_ ? 1 : WPB_ * SUBS;
+    static_assert(!SPLIT_ || (LPW_ == 64 && WPB_ == PARTS), "a split workgroup is PARTS wavefronts on one walker");
 };
 using PackWide = Pack<64, KMAX, true, WAVES_PER_BLOCK>;
 using PackWideFull = Pack<64, KMAX, false, WAVES_PER_BLOCK>;   // the headline shape: no tail code
+using PackSplit = Pack<64, KMAX, true, PARTS, true>;
+using PackSplitFull = Pack<64, KMAX, false, PARTS, true>;
 // 8 walkers x 3.7 KB of LDS per 128-thread workgroup: 5 workgroups (10 waves) per CU
 using PackSmall = Pack<16, 8, true, 2>;
 
@@ -105,9 +124,17 @@ struct WalkerLds {
     LineRec line[KCAP];
     double dtab[KCAP][vamp::DTAB_N];
     float linef[KCAP][4];  // fp32 path: c, s, y, amp
-    double ffval[FF_NODES]; // far-field optical depth at the tile's Chebyshev nodes, then its coefficients
-    int farlist[KCAP];      // lines treated through the far field in the current tile
 };
+struct TileScratch {        // per wavefront: far-field working set of the tile in flight
+    double ffval[FF_NODES]; // optical depth of the far lines at the tile's Chebyshev nodes, then its coefficients
+    int farlist[KMAX];      // lines treated through the far field
+};
+// barrier over the lanes that stage and sweep one walker together
+template <class PK>
+__device__ __forceinline__ void group_barrier() {
+    if constexpr (PK::SPLIT) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();
+}
 using WaveLds = WalkerLds<KMAX>;      // the one-walker-per-wavefront kernels (k_model, k_line_records)
 
 // ---------------------------------------------------------------------------------------
@@ -133,8 +160,12 @@ __device__ __forceinline__ double uniform_logp(double v, double lo, double hi, d
 // MODE is a compile-time parameter: one specialised kernel per parameterisation, no mode
 // branches in the staging code or in the pixel loop.
 template <int MODE, class PK = PackWide>
-__device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::KCAP>& L, int lane, bool want_f32) {
-    // `lane` is the lane index inside the walker's group (0 .. LPW-1)
+__device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::KCAP>& L, int lane, bool want_f32, int part) {
+    // `lane` is the lane index inside the walker's group (0 .. LPW-1).  In a split workgroup
+    // (`part` = wavefront index) all wavefronts evaluate the records and the prior -- each needs
+    // the prior to decide whether to sweep -- the first one stores them, and the per-line tables
+    // are filled by all 256 threads.
+    const bool writer = !PK::SPLIT || part == 0;
     double lp = 0.0;
     const int K = R.K;
     constexpr int Q = (MODE == VAMP_VOIGT4) ? 4 : 3;
@@ -173,8 +204,8 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
             // its sampler rejects; reject here, before the sweep
             if (!(rec.s < __builtin_huge_val()) || !(rec.y < __builtin_huge_val())) lp = NEG_INF;
         }
-        L.line[lane] = rec;
-        if (want_f32) {
+        if (writer) L.line[lane] = rec;
+        if (want_f32 && writer) {
             L.linef[lane][0] = (float)rec.c; L.linef[lane][1] = (float)rec.s;
             L.linef[lane][2] = (float)rec.y;
             L.linef[lane][3] = (float)(MODE == VAMP_GAUSS3 ? rec.amp : rec.amp * SQRT_PI);   // W4 returns H itself
@@ -184,14 +215,15 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
         lp = uniform_logp(L.theta[R.D - 1], 0.0, 1.0, 0.0);
     }
     lp = wave_sum<PK::LPW>(lp);
-    __builtin_amdgcn_wave_barrier();
+    group_barrier<PK>();
     if (MODE != VAMP_GAUSS3 && !want_f32) {
-        for (int e = lane; e < K * vamp::DTAB_N; e += PK::LPW) {
+        constexpr int STEP = PK::SPLIT ? PK::THREADS : PK::LPW;
+        for (int e = PK::SPLIT ? 64 * part + lane : lane; e < K * vamp::DTAB_N; e += STEP) {
             const int k = e / vamp::DTAB_N, n = e % vamp::DTAB_N;
             L.dtab[k][n] = vamp::core_dtab_entry(n, L.line[k].y);
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    group_barrier<PK>();
     return lp;
 }
 
@@ -294,11 +326,11 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
 template <int MODE, class PK, int T>
 __device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x,
                                             const double* __restrict__ f, const double* __restrict__ wt, int lane,
-                                            int base0, int base1, double& chi) {
+                                            int base0, int base1, int stride, double& chi) {
     const int K = R.K, P = R.P;
     constexpr bool gauss = (MODE == VAMP_GAUSS3);
     constexpr int LPW = PK::LPW;
-    for (int base = base0; base < base1; base += LPW * T) {
+    for (int base = base0; base < base1; base += stride) {
         double xi[T], tau[T];
         int idx[T];
 #pragma unroll
@@ -423,9 +455,10 @@ __device__ __forceinline__ void ff_eval4(const double (&Xin)[4], const double (&
 }
 
 template <int MODE, class PK>
-__device__ __forceinline__ void sweep_range_ff(const RegionDev& R, WalkerLds<PK::KCAP>& L, const double* __restrict__ dct,
+__device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
                                                const double* __restrict__ x, const double* __restrict__ f,
-                                               const double* __restrict__ wt, int lane, int base0, int base1, double& chi) {
+                                               const double* __restrict__ wt, int lane, int base0, int base1, int stride,
+                                               double& chi) {
     constexpr int T = TPIX;
     static_assert(PK::LPW == 64 && PK::KCAP <= 16, "far-field tiles: one walker per wavefront, <= 16 lines");
     const int K = R.K;
@@ -435,7 +468,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, WalkerLds<PK:
     const int kk = lane < K ? lane : 0;
     const double my_c = L.line[kk].c;
     const double my_w8 = sqrt(fmax(vamp::R2_CORE - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
-    for (int base = base0; base < base1; base += 64 * T) {
+    for (int base = base0; base < base1; base += stride) {
         double xi[T], tau[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -451,7 +484,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, WalkerLds<PK:
         const bool my_far = lane < K && dist >= FF_DIST * half && dist >= my_w8;
         const unsigned long long farmask = __ballot(my_far);
         const int nfar = __builtin_popcountll(farmask);
-        if (my_far) L.farlist[__builtin_popcountll(farmask & ((1ull << lane) - 1ull))] = lane;
+        if (my_far) Sx.farlist[__builtin_popcountll(farmask & ((1ull << lane) - 1ull))] = lane;
         for (int k = 0; k < K; ++k) {
             if ((farmask >> k) & 1ull) continue;
             const LineRec ln = L.line[k];
@@ -471,7 +504,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, WalkerLds<PK:
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int q = 4 * t + grp;
-                const int k = L.farlist[q < nfar ? q : nfar - 1];
+                const int k = Sx.farlist[q < nfar ? q : nfar - 1];
                 Xn[t] = fabs(xnode - L.line[k].c) * L.line[k].s;
                 yn[t] = L.line[k].y;
                 an[t] = q < nfar ? L.line[k].amp : 0.0;
@@ -481,13 +514,13 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, WalkerLds<PK:
             fs += __shfl_xor(fs, 16, 64);
             fs += __shfl_xor(fs, 32, 64);
             // 2. Chebyshev coefficients: c_m = (2/16) sum_j f_j cos(m pi (j + 1/2) / 16); lane m owns row m
-            if (lane < FF_NODES) L.ffval[lane] = fs;
+            if (lane < FF_NODES) Sx.ffval[lane] = fs;
             __builtin_amdgcn_wave_barrier();
             double cm = 0.0;
 #pragma unroll
-            for (int j = 0; j < FF_NODES; ++j) cm = fma(dct[j * FF_NODES + node], L.ffval[j], cm);
+            for (int j = 0; j < FF_NODES; ++j) cm = fma(dct[j * FF_NODES + node], Sx.ffval[j], cm);
             __builtin_amdgcn_wave_barrier();
-            if (lane < FF_NODES) L.ffval[lane] = cm;
+            if (lane < FF_NODES) Sx.ffval[lane] = cm;
             __builtin_amdgcn_wave_barrier();
             // 3. Clenshaw at the tile's pixels
             const double inv_half = 1.0 / half;
@@ -500,7 +533,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, WalkerLds<PK:
             }
 #pragma unroll
             for (int m = FF_NODES - 1; m >= 1; --m) {
-                const double c = L.ffval[m];
+                const double c = Sx.ffval[m];
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const double b0 = fma(tt2[t], b1[t], c - b2[t]);
@@ -508,7 +541,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, WalkerLds<PK:
                     b1[t] = b0;
                 }
             }
-            const double c0h = 0.5 * L.ffval[0];
+            const double c0h = 0.5 * Sx.ffval[0];
 #pragma unroll
             for (int t = 0; t < T; ++t) tau[t] += fma(0.5 * tt2[t], b1[t], c0h - b2[t]);
             __builtin_amdgcn_wave_barrier();
@@ -526,19 +559,6 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, WalkerLds<PK:
 #ifndef VAMP_FARFIELD
 #define VAMP_FARFIELD 1
 #endif
-
-template <int MODE, class PK = PackWide>
-__device__ __forceinline__ double sweep_f64(const RegionDev& R, WalkerLds<PK::KCAP>& L, const double* __restrict__ dct,
-                                            const double* __restrict__ x, const double* __restrict__ f,
-                                            const double* __restrict__ wt, int lane) {
-    double chi = 0.0;
-    const int full = (R.P / (PK::LPW * TPIX)) * (PK::LPW * TPIX);
-    if constexpr (VAMP_FARFIELD && PK::SUBS == 1 && MODE != VAMP_GAUSS3 && TPIX == 4)
-        sweep_range_ff<MODE, PK>(R, L, dct, x, f, wt, lane, 0, full, chi);
-    else if (TPIX > 1) sweep_range<MODE, PK, TPIX>(R, L, x, f, wt, lane, 0, full, chi);
-    if constexpr (PK::TAIL || TPIX == 1) sweep_range<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, chi);
-    return wave_sum<PK::LPW>(chi);
-}
 
 // fp32 pixel arithmetic (Humlicek W4), chi^2 accumulated in fp64 (SURVEY section 7 hard parts).
 // Same shape as the fp64 sweep: TPIX pixels per lane in full tiles and one wave-uniform region per
@@ -565,11 +585,11 @@ __device__ __forceinline__ void tile_w4(float y, const float (&X)[T], float (&H)
 template <int MODE, class PK, int T>
 __device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const float* __restrict__ x,
                                                 const float* __restrict__ f, const float* __restrict__ wt, int lane,
-                                                int base0, int base1, double& chi) {
+                                                int base0, int base1, int stride, double& chi) {
     const int K = R.K, P = R.P;
     constexpr bool gauss = (MODE == VAMP_GAUSS3);
     constexpr int LPW = PK::LPW;
-    for (int base = base0; base < base1; base += LPW * T) {
+    for (int base = base0; base < base1; base += stride) {
         float xi[T], tau[T];
         int idx[T];
 #pragma unroll
@@ -606,14 +626,62 @@ __device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const Walker
     }
 }
 
-template <int MODE, class PK = PackWide>
-__device__ __forceinline__ double sweep_f32(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const float* __restrict__ x,
-                                            const float* __restrict__ f, const float* __restrict__ wt, int lane) {
-    double chi = 0.0;
-    const int full = (R.P / (PK::LPW * TPIX)) * (PK::LPW * TPIX);
-    if (TPIX > 1) sweep_range_f32<MODE, PK, TPIX>(R, L, x, f, wt, lane, 0, full, chi);
-    if constexpr (PK::TAIL || TPIX == 1) sweep_range_f32<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, chi);
-    return wave_sum<PK::LPW>(chi);
+struct PixPtrs {
+    const double* x; const double* f; const double* wt;       // fp64 copies
+    const float* xf; const float* ff; const float* wtf;       // fp32 copies (may be null)
+};
+
+// Sum over the walker's pixels of ((f - m) w)^2, on every lane.  One walker per wavefront (LPW = 64):
+// full tiles are dealt round-robin into PARTS classes, each class is summed over its tiles and
+// over the wave, and the class sums are added in class order -- by this wavefront (SPLIT = false)
+// or through `red` by the PARTS wavefronts of the workgroup (SPLIT = true, `part` = this wave's
+// class): both give the same bits.  The tail (pixels beyond the last full tile) belongs to class 0.
+template <bool F32, int MODE, class PK>
+__device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
+                                            const PixPtrs& px, int lane, int base0, int full, int stride, bool tail, double& chi) {
+    if constexpr (F32) {
+        const float* x = px.xf + R.pix_off; const float* f = px.ff + R.pix_off; const float* wt = px.wtf + R.pix_off;
+        if (TPIX > 1) sweep_range_f32<MODE, PK, TPIX>(R, L, x, f, wt, lane, base0, full, stride, chi);
+        if constexpr (PK::TAIL || TPIX == 1)
+            if (tail) sweep_range_f32<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, PK::LPW, chi);
+    } else {
+        const double* x = px.x + R.pix_off; const double* f = px.f + R.pix_off; const double* wt = px.wt + R.pix_off;
+        if constexpr (VAMP_FARFIELD && PK::SUBS == 1 && MODE != VAMP_GAUSS3 && TPIX == 4)
+            sweep_range_ff<MODE, PK>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi);
+        else if (TPIX > 1) sweep_range<MODE, PK, TPIX>(R, L, x, f, wt, lane, base0, full, stride, chi);
+        if constexpr (PK::TAIL || TPIX == 1)
+            if (tail) sweep_range<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, PK::LPW, chi);
+    }
+}
+
+template <bool F32, int MODE, class PK = PackWide>
+__device__ __forceinline__ double sweep_pixels(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
+                                               const PixPtrs& px, int lane, int part, double* red) {
+    constexpr int TILE = PK::LPW * TPIX;
+    const int full = (R.P / TILE) * TILE;
+    if constexpr (PK::SUBS > 1) {            // several walkers per wavefront: short regions, one pass
+        double chi = 0.0;
+        sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, 0, full, TILE, true, chi);
+        return wave_sum<PK::LPW>(chi);
+    } else if constexpr (PK::SPLIT) {
+        double chi = 0.0;
+        sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, part * TILE, full, PARTS * TILE, part == 0, chi);
+        chi = wave_sum<64>(chi);
+        if (lane == 0) red[part] = chi;
+        __syncthreads();
+        double total = 0.0;
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p) total += red[p];
+        return total;
+    } else {
+        double total = 0.0;
+        for (int p = 0; p < PARTS; ++p) {
+            double chi = 0.0;
+            sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, p * TILE, full, PARTS * TILE, p == 0, chi);
+            total += wave_sum<64>(chi);
+        }
+        return total;
+    }
 }
 
 // log-likelihood from the reduced sum (both forms of SURVEY Appendix A)
@@ -627,25 +695,18 @@ __device__ __forceinline__ double loglike_from_sum(const RegionDev& R, const LDS
     return -0.5 * ssum + R.norm_const;                                            // vpfits.py:118
 }
 
-struct PixPtrs {
-    const double* x; const double* f; const double* wt;       // fp64 copies
-    const float* xf; const float* ff; const float* wtf;       // fp32 copies (may be null)
-};
-
 // log-posterior of the walker whose parameters sit in L.theta; `lane` = lane inside the walker's
 // group.  Groups of one wave may leave early independently: everything below communicates only
 // inside a group (xor shuffles with offsets < LPW) or through __any, which ignores inactive lanes.
 template <bool F32, int MODE, class PK = PackWide>
-__device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::KCAP>& L, const double* dct, const PixPtrs& px,
-                                              int lane, double* chi_out) {
-    const double lp = stage_lines<MODE, PK>(R, L, lane, F32);
+__device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* dct,
+                                              const PixPtrs& px, int lane, double* chi_out, int part, double* red) {
+    const double lp = stage_lines<MODE, PK>(R, L, lane, F32, part);
     if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
         if (chi_out) *chi_out = __builtin_nan("");
         return NEG_INF;
     }
-    double ssum;
-    if constexpr (F32) ssum = sweep_f32<MODE, PK>(R, L, px.xf + R.pix_off, px.ff + R.pix_off, px.wtf + R.pix_off, lane);
-    else ssum = sweep_f64<MODE, PK>(R, L, dct, px.x + R.pix_off, px.f + R.pix_off, px.wt + R.pix_off, lane);
+    const double ssum = sweep_pixels<F32, MODE, PK>(R, L, Sx, dct, px, lane, part, red);
     if (chi_out) *chi_out = ssum;
     double v = lp + loglike_from_sum(R, L, ssum);
     if (v != v) v = NEG_INF;                 // NaN -> -inf (emcee convention)
@@ -659,19 +720,23 @@ template <bool F32, int MODE, class PK>
 __global__ __launch_bounds__(PK::THREADS, 3) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
                                                   long long W, const double* __restrict__ theta,
                                                   double* __restrict__ lnprob, double* __restrict__ chi2) {
-    __shared__ WalkerLds<PK::KCAP> lds[PK::WALKERS_PER_BLOCK];
+    __shared__ WalkerLds<PK::KCAP> lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
+    __shared__ TileScratch scr[PK::WPB];
     __shared__ double dct[FF_TABLE];
+    __shared__ double red[PARTS];
     ff_fill_table(dct);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
-    const long long w = ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS + sub;
+    const long long w = PK::SPLIT ? (long long)blockIdx.x : ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS + sub;
     if (w >= W) return;
     const RegionDev R = regions[region];
-    WalkerLds<PK::KCAP>& L = lds[wave * PK::SUBS + sub];
-    for (int d = l; d < R.D; d += PK::LPW) L.theta[d] = theta[w * R.D + d];
-    __builtin_amdgcn_wave_barrier();
+    WalkerLds<PK::KCAP>& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
+    if (!PK::SPLIT || wave == 0)
+        for (int d = l; d < R.D; d += PK::LPW) L.theta[d] = theta[w * R.D + d];
+    group_barrier<PK>();
     double chi;
-    const double v = wave_lnprob<F32, MODE, PK>(R, L, dct, px, l, &chi);
+    const double v = wave_lnprob<F32, MODE, PK>(R, L, scr[wave], dct, px, l, &chi, wave, red);
+    if (PK::SPLIT && wave != 0) return;
     if (l == 0) {
         lnprob[w] = v;
         if (chi2) chi2[w] = chi;
@@ -689,7 +754,7 @@ __global__ __launch_bounds__(BLOCK) void k_model(const RegionDev* __restrict__ r
     WaveLds& L = lds[wave];
     for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[d];
     __builtin_amdgcn_wave_barrier();
-    (void)stage_lines<MODE>(R, L, lane, false);
+    (void)stage_lines<MODE>(R, L, lane, false, 0);
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= R.P) return;
     const double xi = px.x[R.pix_off + i];
@@ -720,7 +785,7 @@ __global__ __launch_bounds__(64) void k_line_records(const RegionDev* __restrict
     WaveLds& L = lds[0];
     for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[d];
     __builtin_amdgcn_wave_barrier();
-    const double lp = stage_lines<MODE>(R, L, lane, false);
+    const double lp = stage_lines<MODE>(R, L, lane, false, 0);
     if (lane < R.K) {
         rec[5 * lane + 0] = L.line[lane].c;
         rec[5 * lane + 1] = L.line[lane].s;
@@ -813,8 +878,10 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
                                                      long long ext_n, const int* __restrict__ ext_active,
                                                      const int* __restrict__ ext_partner, const double* __restrict__ ext_z,
                                                      const double* __restrict__ ext_logu) {
-    __shared__ WalkerLds<PK::KCAP> lds[PK::WALKERS_PER_BLOCK];
+    __shared__ WalkerLds<PK::KCAP> lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
+    __shared__ TileScratch scr[PK::WPB];
     __shared__ double dct[FF_TABLE];
+    __shared__ double red[PARTS];
     ff_fill_table(dct);
     const int lane = threadIdx.x & 63;
     // the wave index is the same in every lane: say so, and the draws below (Philox rounds, the
@@ -822,7 +889,8 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
     const long long halfW = S.W >> 1;
-    const long long slot0 = ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS;   // first walker of this wave
+    // first walker of this wave (a split workgroup: the one walker all of its waves serve)
+    const long long slot0 = PK::SPLIT ? (long long)blockIdx.x : ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS;
     long long slot = slot0 + sub;
     int region;
     long long ws, wc;            // local walker ids (within the region) of mover and partner
@@ -859,15 +927,17 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
         logu = u2 > 0.0 ? log(u2) : NEG_INF;
     }
     const RegionDev R = S.regions[region];
-    WalkerLds<PK::KCAP>& L = lds[wave * PK::SUBS + sub];
+    WalkerLds<PK::KCAP>& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
     double* Xs = S.X + R.theta_off + ws * R.D;
     const double* Xc = S.X + R.theta_off + wc * R.D;
-    for (int d = l; d < R.D; d += PK::LPW) {
-        const double c = Xc[d];
-        L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
-    }
-    __builtin_amdgcn_wave_barrier();
-    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, dct, px, l, nullptr);
+    if (!PK::SPLIT || wave == 0)
+        for (int d = l; d < R.D; d += PK::LPW) {
+            const double c = Xc[d];
+            L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
+        }
+    group_barrier<PK>();
+    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, scr[wave], dct, px, l, nullptr, wave, red);
+    if (PK::SPLIT && wave != 0) return;     // the group's first wave carries out the accept step
     const long long wg = R.walker_off + ws;
     const double lnp_s = S.lnp[wg];
     const double diff = (double)(R.D - 1) * log(z) + lnp_q - lnp_s;
@@ -914,9 +984,11 @@ struct DevBuf {
         else { constexpr int M = VAMP_NBZ3; __VA_ARGS__; }                      \
     } while (0)
 #define VAMP_FOR_MODE(mode, ...) VAMP_FOR_MODE_(mode, __VA_ARGS__)
-#define VAMP_FOR_MODE_PK(mode, small, ...)                                      \
+#define VAMP_FOR_MODE_PK(mode, small, split, ...)                                      \
     do {                                                                        \
         if (small) { using PK = PackSmall; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        else if (split && c->full_tiles) { using PK = PackSplitFull; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        else if (split) { using PK = PackSplit; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else if (c->full_tiles) { using PK = PackWideFull; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else { using PK = PackWide; VAMP_FOR_MODE_(mode, __VA_ARGS__); }        \
     } while (0)
@@ -933,7 +1005,8 @@ struct vamp_ctx {
     // regions
     int n_regions = 0;
     int mode = VAMP_VOIGT4;
-    int packing = 0;       // requested: 0 = auto, 16 or 64 lanes per walker
+    int packing = 0;       // requested: 0 = auto, 16 or 64 lanes per walker, 256 = a 4-wave workgroup per walker
+    int min_tiles = 0;     // full 256-pixel tiles of the shortest region
     bool packed = false;   // regions qualify for <16, 8> (every K <= 8, short regions)
     bool full_tiles = false;   // every region's pixel count is a multiple of 64 * TPIX
     std::vector<RegionDev> regions_h;
@@ -1009,6 +1082,13 @@ int flush_timing(vamp_ctx* c) {
     return 0;
 }
 
+// one walker per 4-wave workgroup?  (same bits either way: see Pack)
+bool use_split(const vamp_ctx* c, long long n_walkers, bool small) {
+    if (small) return false;
+    if (c->packing == 256) return true;
+    return c->packing == 0 && c->min_tiles >= 2 * PARTS && n_walkers < SPLIT_MAX_WALKERS;
+}
+
 int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n) {
     SamplerDev S;
     S.regions = c->regions_d;
@@ -1030,7 +1110,8 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     // below that a wave per walker has the shorter critical path)
     const bool small = c->packed && !ext && (c->W / 2) % subs == 0 && (c->split_block / 2) % subs == 0 &&
                        (c->packing == 16 || n >= PACK_MIN_WALKERS);
-    const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : PackWide::WALKERS_PER_BLOCK;
+    const bool split = use_split(c, n, small);
+    const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : split ? 1 : PackWide::WALKERS_PER_BLOCK;
     const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
     const unsigned threads = small ? PackSmall::THREADS : PackWide::THREADS;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1055,19 +1136,19 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     const PixPtrs px = c->pix();
     if (ext) {
         if (c->f32)
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<true, true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_half_step<true, true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
                                                       half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d));
         else
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<false, true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_half_step<false, true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
                                                       half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d));
     } else {
         const int* ni = nullptr;
         const double* nd = nullptr;
         if (c->f32)
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<true, false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_half_step<true, false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
                                                       half, 0, 0ll, ni, ni, nd, nd));
         else
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_half_step<false, false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
+            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_half_step<false, false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
                                                       half, 0, 0ll, ni, ni, nd, nd));
     }
     HIP_TRY(hipGetLastError());
@@ -1140,8 +1221,8 @@ int vamp_ctx_set_stream(vamp_ctx* c, void* hip_stream) {
 
 int vamp_ctx_set_packing(vamp_ctx* c, int lanes_per_walker) {
     if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: ctx is NULL");
-    if (lanes_per_walker != 0 && lanes_per_walker != 16 && lanes_per_walker != 64)
-        return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: lanes_per_walker must be 0 (auto), 16 or 64");
+    if (lanes_per_walker != 0 && lanes_per_walker != 16 && lanes_per_walker != 64 && lanes_per_walker != 256)
+        return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: lanes_per_walker must be 0 (auto), 16, 64 or 256");
     c->packing = lanes_per_walker;
     return VAMP_OK;
 }
@@ -1244,13 +1325,15 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         if (c->packing == 16) {
             if (kmax > PackSmall::KCAP) return fail(VAMP_ERR_ARG, "vamp_set_regions: 16-lane packing supports at most 8 components per region");
             c->packed = true;
-        } else if (c->packing == 64) {
+        } else if (c->packing == 64 || c->packing == 256) {
             c->packed = false;
         } else {
             c->packed = kmax <= PackSmall::KCAP && mean_p <= 128.0;
         }
         c->full_tiles = true;
         for (int r = 0; r < n_regions; ++r) c->full_tiles = c->full_tiles && (R[r].P % (64 * TPIX) == 0);
+        c->min_tiles = R[0].P / (64 * TPIX);
+        for (int r = 1; r < n_regions; ++r) c->min_tiles = std::min(c->min_tiles, R[r].P / (64 * TPIX));
     }
     c->regions_h = R;
     c->mode = mode;
@@ -1291,14 +1374,15 @@ int vamp_lnprob(vamp_ctx* c, int region, int64_t W, const double* theta, double*
     double *th_d = c->sc_th, *lp_d = c->sc_lp, *ch_d = chi2 ? c->sc_chi : nullptr;
     HIP_TRY(hipMemcpyAsync(th_d, theta, nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const bool small = c->packed && (c->packing == 16 || W >= PACK_MIN_WALKERS);
-    const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : PackWide::WALKERS_PER_BLOCK;
+    const bool split = use_split(c, W, small);
+    const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : split ? 1 : PackWide::WALKERS_PER_BLOCK;
     const unsigned grid = (unsigned)((W + per_block - 1) / per_block);
     const unsigned threads = small ? PackSmall::THREADS : PackWide::THREADS;
     if (c->f32)
-        VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, region,
+        VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, region,
                                                   c->pix(), (long long)W, th_d, lp_d, ch_d));
     else
-        VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, region,
+        VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, region,
                                                   c->pix(), (long long)W, th_d, lp_d, ch_d));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(lnprob, lp_d, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1414,15 +1498,16 @@ int vamp_sampler_init(vamp_ctx* c, int64_t W, const double* theta0, uint64_t see
     for (int r = 0; r < c->n_regions; ++r) {
         const RegionDev& R = c->regions_h[r];
         const bool small = c->packed && (c->packing == 16 || W >= PACK_MIN_WALKERS);
-        const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : PackWide::WALKERS_PER_BLOCK;
+        const bool split = use_split(c, W, small);
+        const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : split ? 1 : PackWide::WALKERS_PER_BLOCK;
         const unsigned grid = (unsigned)((W + per_block - 1) / per_block);
         const unsigned threads = small ? PackSmall::THREADS : PackWide::THREADS;
         double* nochi = nullptr;
         if (c->f32)
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, r,
+            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, r,
                                                       c->pix(), (long long)W, c->X_d + R.theta_off, c->lnp_d + R.walker_off, nochi));
         else
-            VAMP_FOR_MODE_PK(c->mode, small, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, r,
+            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, r,
                                                       c->pix(), (long long)W, c->X_d + R.theta_off, c->lnp_d + R.walker_off, nochi));
         HIP_TRY(hipGetLastError());
     }
