@@ -339,10 +339,11 @@ def test_rare_branches_in_long_regions(hip_ctx):
 
 
 @pytest.mark.parametrize("P", [4096, 3000, 200])
-def test_split_workgroup_is_bit_identical(P):
-    """One walker per wavefront (packing 64) and one walker per 4-wavefront workgroup (packing
-    256: each wavefront sweeps every 4th tile) sum chi^2 in the same order: identical lnprob bits
-    and identical stretch-move trajectories, with and without a ragged tail, fp64 and fp32."""
+def test_split_workgroup_matches_wave_per_walker(P):
+    """One walker per wavefront (packing 64) against one walker per 4-wavefront workgroup (packing
+    256: each wavefront sweeps every 4th tile).  Both sum chi^2 in the same order.  fp32: identical
+    bits and identical stretch-move trajectories.  fp64: the workgroup evaluates the line cores
+    through per-line Taylor tables (absolute error 2e-16 in H), so lnprob agrees to rounding."""
     import vamp_amd
     from bench import make_workload
     wl = make_workload(P=P, K=5, W=64, seed=11, nbz=False)
@@ -358,6 +359,10 @@ def test_split_workgroup_is_bit_identical(P):
             X, lp, nacc, _ = ctx.get_state()
             got.append((lnp, X, lp, nacc))
             ctx.close()
-        for a, b in zip(*got):
-            assert np.array_equal(a, b)
         assert np.isfinite(got[0][0]).all() and got[0][3].sum() > 0
+        if dtype == vamp_amd.F32:
+            for a, b in zip(*got):
+                assert np.array_equal(a, b)
+        else:
+            a, b = got[0][0], got[1][0]
+            assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(a))) <= 1e-12

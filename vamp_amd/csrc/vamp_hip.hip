@@ -41,10 +41,11 @@ constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
 constexpr int DMAX = 4 * KMAX + 1;
 constexpr long long PACK_MIN_WALKERS = 16384;   // automatic packing: walkers per launch needed to pay off
-// automatic splitting of a walker over the 4 waves of a workgroup: launches below this many walkers
-// (5 rounds of the chip's 3072 wavefront slots) whose regions give every wave >= 2 tiles
+// automatic choice of a 4-wave workgroup per walker (shared Taylor tables of the line cores, see
+// LineTables): regions that give every wave >= 2 tiles.  The choice must not depend on the launch
+// size: a shard of an ensemble has to run the same arithmetic as the whole ensemble on one GPU.
 #ifndef VAMP_SPLIT_MAX_WALKERS
-#define VAMP_SPLIT_MAX_WALKERS 16384
+#define VAMP_SPLIT_MAX_WALKERS (1ll << 62)
 #endif
 constexpr long long SPLIT_MAX_WALKERS = VAMP_SPLIT_MAX_WALKERS;
 
@@ -129,6 +130,13 @@ struct TileScratch {        // per wavefront: far-field working set of the tile 
     double ffval[FF_NODES]; // optical depth of the far lines at the tile's Chebyshev nodes, then its coefficients
     int farlist[KMAX];      // lines treated through the far field
 };
+// Taylor tables of the near-axis zone of every line of ONE walker (voigt_math.hpp): 36 KiB, which
+// only a workgroup that serves a single walker can afford (3 workgroups per CU).
+template <bool ON>
+struct alignas(16) LineTables { double a[ON ? KMAX * vamp::TAB_LINE : 2]; };
+template <bool F32, int MODE, class PK>
+constexpr bool use_tables() { return PK::SPLIT && !F32 && MODE != VAMP_GAUSS3; }
+
 // barrier over the lanes that stage and sweep one walker together
 template <class PK>
 __device__ __forceinline__ void group_barrier() {
@@ -159,8 +167,9 @@ __device__ __forceinline__ double uniform_logp(double v, double lo, double hi, d
 // Turn theta (in LDS) into line records + prior.  Returns log-prior on every lane.
 // MODE is a compile-time parameter: one specialised kernel per parameterisation, no mode
 // branches in the staging code or in the pixel loop.
-template <int MODE, class PK = PackWide>
-__device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::KCAP>& L, int lane, bool want_f32, int part) {
+template <int MODE, class PK = PackWide, bool TAB = false>
+__device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::KCAP>& L, int lane, bool want_f32, int part,
+                                              double* tab = nullptr) {
     // `lane` is the lane index inside the walker's group (0 .. LPW-1).  In a split workgroup
     // (`part` = wavefront index) all wavefronts evaluate the records and the prior -- each needs
     // the prior to decide whether to sweep -- the first one stores them, and the per-line tables
@@ -224,6 +233,15 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
         }
     }
     group_barrier<PK>();
+    if constexpr (TAB) {
+        // one (line, interval) pair per thread: 16 lines x 16 intervals = the 256 threads of the group
+        for (int e = 64 * part + lane; e < K * vamp::TAB_NI; e += PK::THREADS) {
+            const int k = e / vamp::TAB_NI, i = e % vamp::TAB_NI;
+            vamp::taylor_table_row(i, L.line[k].y, L.dtab[k], L.line[k].pole, L.line[k].hy,
+                                   tab + k * vamp::TAB_LINE + i * vamp::TAB_NT);
+        }
+        group_barrier<PK>();
+    }
     return lp;
 }
 
@@ -245,8 +263,29 @@ __device__ __forceinline__ void tile_jfrac(const double (&X)[T], const double (&
     if (t < T) H[t] = vamp::voigt_jfrac<M>(X[t], y, r2[t]);
 }
 
-template <int T>
-__device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab, const double (&Xin)[T], double (&H)[T]) {
+// sqrt(pi) H from the line's Taylor table, 0 <= x < 8: nine 16-byte LDS reads + 17 fused multiply-adds
+__device__ __forceinline__ double table_eval(const double* tab, double x) {
+    const int i = (int)(x * 2.0);
+    const double d = fma((double)i, -vamp::CORE_H, x) - 0.5 * vamp::CORE_H;
+    static_assert(vamp::TAB_NT == 18, "nine coefficient pairs below");
+    const double2* a = reinterpret_cast<const double2*>(tab + i * vamp::TAB_NT);
+    const double2 c8 = a[8], c7 = a[7], c6 = a[6], c5 = a[5], c4 = a[4], c3 = a[3], c2 = a[2], c1 = a[1], c0 = a[0];
+    double r = fma(c8.y, d, c8.x);
+    r = fma(r, d, c7.y); r = fma(r, d, c7.x);
+    r = fma(r, d, c6.y); r = fma(r, d, c6.x);
+    r = fma(r, d, c5.y); r = fma(r, d, c5.x);
+    r = fma(r, d, c4.y); r = fma(r, d, c4.x);
+    r = fma(r, d, c3.y); r = fma(r, d, c3.x);
+    r = fma(r, d, c2.y); r = fma(r, d, c2.x);
+    r = fma(r, d, c1.y); r = fma(r, d, c1.x);
+    r = fma(r, d, c0.y); r = fma(r, d, c0.x);
+    return r;
+}
+
+// `tab` (TAB = true): the line's Taylor table replaces the near-axis rule for |z|^2 < 64
+template <int T, bool TAB = false>
+__device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab, const double (&Xin)[T], double (&H)[T],
+                                           const double* tab = nullptr) {
     const double y = ln.y;
     const double y2 = y * y;
     // narrow line: |z| spans many units (possibly decades) inside one tile, and a lane promoted to a
@@ -285,8 +324,12 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
             if (__any(lo < vamp::R2_CORE)) {
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    if (r2[t] < vamp::R2_CORE) H[t] = vamp::voigt_core(X[t], y, dtab, ln.pole, ln.hy);
-                    else H[t] = vamp::voigt_jfrac<6>(X[t], y, r2[t]);
+                    if (r2[t] < vamp::R2_CORE) {
+                        if constexpr (TAB) H[t] = table_eval(tab, X[t]);
+                        else H[t] = vamp::voigt_core(X[t], y, dtab, ln.pole, ln.hy);
+                    } else {
+                        H[t] = vamp::voigt_jfrac<6>(X[t], y, r2[t]);
+                    }
                 }
                 if (y < vamp::Y_TINY) {
 #pragma unroll
@@ -323,10 +366,10 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
 // Full tiles: a lane holds TPIX pixels (i, i+LPW, ...) per iteration -- TPIX independent dependency
 // chains and one LDS read of the line record per TPIX evaluations; the remaining pixels of the
 // region run one per lane.
-template <int MODE, class PK, int T>
+template <int MODE, class PK, int T, bool TAB = false>
 __device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x,
                                             const double* __restrict__ f, const double* __restrict__ wt, int lane,
-                                            int base0, int base1, int stride, double& chi) {
+                                            int base0, int base1, int stride, double& chi, const double* tab = nullptr) {
     const int K = R.K, P = R.P;
     constexpr bool gauss = (MODE == VAMP_GAUSS3);
     constexpr int LPW = PK::LPW;
@@ -355,7 +398,7 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<
                 double X[T], H[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t) X[t] = fabs(xi[t] - ln.c) * ln.s;
-                tile_voigt<T>(ln, L.dtab[k], X, H);
+                tile_voigt<T, TAB>(ln, L.dtab[k], X, H, TAB ? tab + k * vamp::TAB_LINE : nullptr);
 #pragma unroll
                 for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
             }
@@ -454,11 +497,11 @@ __device__ __forceinline__ void ff_eval4(const double (&Xin)[4], const double (&
     }
 }
 
-template <int MODE, class PK>
+template <int MODE, class PK, bool TAB>
 __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
                                                const double* __restrict__ x, const double* __restrict__ f,
                                                const double* __restrict__ wt, int lane, int base0, int base1, int stride,
-                                               double& chi) {
+                                               double& chi, const double* tab) {
     constexpr int T = TPIX;
     static_assert(PK::LPW == 64 && PK::KCAP <= 16, "far-field tiles: one walker per wavefront, <= 16 lines");
     const int K = R.K;
@@ -491,7 +534,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
             double X[T], H[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) X[t] = fabs(xi[t] - ln.c) * ln.s;
-            tile_voigt<T>(ln, L.dtab[k], X, H);
+            tile_voigt<T, TAB>(ln, L.dtab[k], X, H, TAB ? tab + k * vamp::TAB_LINE : nullptr);
 #pragma unroll
             for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
         }
@@ -638,7 +681,9 @@ struct PixPtrs {
 // class): both give the same bits.  The tail (pixels beyond the last full tile) belongs to class 0.
 template <bool F32, int MODE, class PK>
 __device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
-                                            const PixPtrs& px, int lane, int base0, int full, int stride, bool tail, double& chi) {
+                                            const PixPtrs& px, int lane, int base0, int full, int stride, bool tail, double& chi,
+                                            const double* tab) {
+    constexpr bool TAB = use_tables<F32, MODE, PK>();
     if constexpr (F32) {
         const float* x = px.xf + R.pix_off; const float* f = px.ff + R.pix_off; const float* wt = px.wtf + R.pix_off;
         if (TPIX > 1) sweep_range_f32<MODE, PK, TPIX>(R, L, x, f, wt, lane, base0, full, stride, chi);
@@ -647,25 +692,25 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<
     } else {
         const double* x = px.x + R.pix_off; const double* f = px.f + R.pix_off; const double* wt = px.wt + R.pix_off;
         if constexpr (VAMP_FARFIELD && PK::SUBS == 1 && MODE != VAMP_GAUSS3 && TPIX == 4)
-            sweep_range_ff<MODE, PK>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi);
-        else if (TPIX > 1) sweep_range<MODE, PK, TPIX>(R, L, x, f, wt, lane, base0, full, stride, chi);
+            sweep_range_ff<MODE, PK, TAB>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi, tab);
+        else if (TPIX > 1) sweep_range<MODE, PK, TPIX, TAB>(R, L, x, f, wt, lane, base0, full, stride, chi, tab);
         if constexpr (PK::TAIL || TPIX == 1)
-            if (tail) sweep_range<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, PK::LPW, chi);
+            if (tail) sweep_range<MODE, PK, 1, TAB>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, PK::LPW, chi, tab);
     }
 }
 
 template <bool F32, int MODE, class PK = PackWide>
 __device__ __forceinline__ double sweep_pixels(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
-                                               const PixPtrs& px, int lane, int part, double* red) {
+                                               const PixPtrs& px, int lane, int part, double* red, const double* tab) {
     constexpr int TILE = PK::LPW * TPIX;
     const int full = (R.P / TILE) * TILE;
     if constexpr (PK::SUBS > 1) {            // several walkers per wavefront: short regions, one pass
         double chi = 0.0;
-        sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, 0, full, TILE, true, chi);
+        sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, 0, full, TILE, true, chi, tab);
         return wave_sum<PK::LPW>(chi);
     } else if constexpr (PK::SPLIT) {
         double chi = 0.0;
-        sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, part * TILE, full, PARTS * TILE, part == 0, chi);
+        sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, part * TILE, full, PARTS * TILE, part == 0, chi, tab);
         chi = wave_sum<64>(chi);
         if (lane == 0) red[part] = chi;
         __syncthreads();
@@ -677,7 +722,7 @@ __device__ __forceinline__ double sweep_pixels(const RegionDev& R, const WalkerL
         double total = 0.0;
         for (int p = 0; p < PARTS; ++p) {
             double chi = 0.0;
-            sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, p * TILE, full, PARTS * TILE, p == 0, chi);
+            sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, p * TILE, full, PARTS * TILE, p == 0, chi, tab);
             total += wave_sum<64>(chi);
         }
         return total;
@@ -700,13 +745,13 @@ __device__ __forceinline__ double loglike_from_sum(const RegionDev& R, const LDS
 // inside a group (xor shuffles with offsets < LPW) or through __any, which ignores inactive lanes.
 template <bool F32, int MODE, class PK = PackWide>
 __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* dct,
-                                              const PixPtrs& px, int lane, double* chi_out, int part, double* red) {
-    const double lp = stage_lines<MODE, PK>(R, L, lane, F32, part);
+                                              const PixPtrs& px, int lane, double* chi_out, int part, double* red, double* tab) {
+    const double lp = stage_lines<MODE, PK, use_tables<F32, MODE, PK>()>(R, L, lane, F32, part, tab);
     if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
         if (chi_out) *chi_out = __builtin_nan("");
         return NEG_INF;
     }
-    const double ssum = sweep_pixels<F32, MODE, PK>(R, L, Sx, dct, px, lane, part, red);
+    const double ssum = sweep_pixels<F32, MODE, PK>(R, L, Sx, dct, px, lane, part, red, tab);
     if (chi_out) *chi_out = ssum;
     double v = lp + loglike_from_sum(R, L, ssum);
     if (v != v) v = NEG_INF;                 // NaN -> -inf (emcee convention)
@@ -724,6 +769,7 @@ __global__ __launch_bounds__(PK::THREADS, 3) void k_lnprob(const RegionDev* __re
     __shared__ TileScratch scr[PK::WPB];
     __shared__ double dct[FF_TABLE];
     __shared__ double red[PARTS];
+    __shared__ LineTables<use_tables<F32, MODE, PK>()> tabs;
     ff_fill_table(dct);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
@@ -735,7 +781,7 @@ __global__ __launch_bounds__(PK::THREADS, 3) void k_lnprob(const RegionDev* __re
         for (int d = l; d < R.D; d += PK::LPW) L.theta[d] = theta[w * R.D + d];
     group_barrier<PK>();
     double chi;
-    const double v = wave_lnprob<F32, MODE, PK>(R, L, scr[wave], dct, px, l, &chi, wave, red);
+    const double v = wave_lnprob<F32, MODE, PK>(R, L, scr[wave], dct, px, l, &chi, wave, red, tabs.a);
     if (PK::SPLIT && wave != 0) return;
     if (l == 0) {
         lnprob[w] = v;
@@ -882,6 +928,7 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
     __shared__ TileScratch scr[PK::WPB];
     __shared__ double dct[FF_TABLE];
     __shared__ double red[PARTS];
+    __shared__ LineTables<use_tables<F32, MODE, PK>()> tabs;
     ff_fill_table(dct);
     const int lane = threadIdx.x & 63;
     // the wave index is the same in every lane: say so, and the draws below (Philox rounds, the
@@ -936,7 +983,7 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
             L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
         }
     group_barrier<PK>();
-    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, scr[wave], dct, px, l, nullptr, wave, red);
+    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, scr[wave], dct, px, l, nullptr, wave, red, tabs.a);
     if (PK::SPLIT && wave != 0) return;     // the group's first wave carries out the accept step
     const long long wg = R.walker_off + ws;
     const double lnp_s = S.lnp[wg];

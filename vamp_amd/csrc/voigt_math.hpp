@@ -321,6 +321,113 @@ VAMP_DEV double voigt_core(double x, double y, const double* dtab, double pole, 
     return H;
 }
 
+// ---- per-line Taylor tables of the near-axis zone ---------------------------------------------
+// For one line (fixed y) sqrt(pi) Re w(x + i y) on 0 <= x < 8 is an entire function of x.  The zone
+// is cut into TAB_NI intervals of width 1/2 (their centres x_i = (i + 1/2)/2 are nodes of the
+// near-axis rule, so the rule needs no exponentials there: the weights are e^{-j^2/4}), and on
+// each the function is its Taylor polynomial of degree TAB_NT - 1 about x_i:
+//     Ws = sqrt(pi) w,  Ws' = -2 z Ws + 2i,  c_0 = Ws(z_i),  c_1 = -2 z_i c_0 + 2i,
+//     c_{n+1} = -2 (z_i c_n + c_{n-1}) / (n + 1),      sqrt(pi) H(x_i + d, y) = sum_n Re(c_n) d^n
+// (d real, |d| <= 1/4).  Measured against 40-digit references for y from 1e-12 to 8: absolute
+// error <= 2e-16, relative <= 2e-14 (tools/gen_voigt_tables.py --check-taylor).  One evaluation is
+// TAB_NT - 1 fused multiply-adds on coefficients read from LDS, against ~180 issue slots for the
+// rule itself; a table costs one rule evaluation (real and imaginary part) per interval.
+constexpr int TAB_NI = 16;            // intervals: [i/2, (i+1)/2)
+constexpr int TAB_NT = 18;            // coefficients per interval (144 B: 16-byte aligned rows)
+constexpr int TAB_LINE = TAB_NI * TAB_NT;   // doubles per line
+
+// sin and cos together, same reduction and kernels as cos_small
+VAMP_DEV void sincos_small(double a, double& sn_out, double& cs_out) {
+    const double k = rint(a * 0.63661977236758138243);
+    double r = fma(-k, 1.57079632673412561417e+00, a);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    const double m = -(r * r);
+    double c = F16;
+    c = fma(c, m, F14);
+    c = fma(c, m, F12);
+    c = fma(c, m, F10);
+    c = fma(c, m, F8);
+    c = fma(c, m, F6);
+    c = fma(c, m, F4);
+    c = fma(c, m, F2);
+    c = fma(c, m, 1.0);
+    double sn = F17;
+    sn = fma(sn, m, F15);
+    sn = fma(sn, m, F13);
+    sn = fma(sn, m, F11);
+    sn = fma(sn, m, F9);
+    sn = fma(sn, m, F7);
+    sn = fma(sn, m, F5);
+    sn = fma(sn, m, F3);
+    sn = fma(sn * m, r, r);
+    const int q = (int)k & 3;                    // angle = r + q pi/2
+    const double cq = (q & 1) ? sn : c, sq = (q & 1) ? c : sn;
+    cs_out = (q == 1 || q == 2) ? -cq : cq;
+    sn_out = (q >= 2) ? -sq : sq;
+}
+
+// sqrt(pi) w(x_i + i y) at the centre of interval i from the line's dtab: the near-axis rule with
+// d = 0, real part as in voigt_core, imaginary part from the same nodes:
+//     sqrt(pi) Im w = (h / sqrt(pi)) sum_n e^{-(x - u_n)^2} u_n / (u_n^2 + y^2) - sqrt(pi) A(y) e^{-x^2} sin(2 x y)
+VAMP_DEV void core_centre(int i, double y, const double* dtab, double pole, double hy, double& re, double& im) {
+    constexpr double CJ[CORE_J + 1] = {1.0, 0.77880078307140486825, 0.3678794411714423216, 0.10539922456186433678,
+                                       0.018315638888734180294, 0.0019304541362277092422, 0.0001234098040866795495,
+                                       4.7851173921290090896e-6, 1.1253517471925911451e-7, 1.6052280551856116087e-9,
+                                       1.3887943864964020595e-11, 7.2877240958196924193e-14, 2.3195228302435693883e-16,
+                                       4.477732441718301199e-19};
+    const double* p = dtab + i + DTAB_OFF;
+    double sre = 0.0, sim = 0.0;
+    for (int j = CORE_J; j >= 1; --j) {          // small terms first
+        const double a = CJ[j] * p[j], b = CJ[j] * p[-j];
+        sre += a + b;
+        sim = fma(a, ((i + j) + 0.5) * CORE_H, fma(b, ((i - j) + 0.5) * CORE_H, sim));
+    }
+    sre += p[0];
+    sim = fma(p[0], (i + 0.5) * CORE_H, sim);
+    const double x = (i + 0.5) * CORE_H;
+    re = hy * sre;
+    im = (CORE_H * INV_SQRT_PI) * sim;
+    if (pole != 0.0) {
+        double sn, cs;
+        sincos_small(2.0 * x * y, sn, cs);
+        const double e = pole * exp_neg_sq(x);
+        re = fma(e, cs, re);
+        im = fma(-e, sn, im);
+    }
+}
+
+// the TAB_NT coefficients of interval i, written to out[0 .. TAB_NT)
+VAMP_DEV void taylor_table_row(int i, double y, const double* dtab, double pole, double hy, double* out) {
+    double c0r, c0i;
+    core_centre(i, y, dtab, pole, hy, c0r, c0i);
+    const double zr = (i + 0.5) * CORE_H, zi = y;
+    // c_1 = -2 z c_0 + 2i
+    double c1r = -2.0 * (zr * c0r - zi * c0i);
+    double c1i = fma(-2.0, fma(zr, c0i, zi * c0r), 2.0);
+    out[0] = c0r;
+    out[1] = c1r;
+    for (int n = 1; n + 1 < TAB_NT; ++n) {
+        const double f = -2.0 / (double)(n + 1);
+        const double nr = f * (fma(zr, c1r, -zi * c1i) + c0r);
+        const double ni = f * (fma(zr, c1i, zi * c1r) + c0i);
+        c0r = c1r; c0i = c1i;
+        c1r = nr; c1i = ni;
+        out[n + 1] = nr;
+    }
+}
+
+// sqrt(pi) H(x, y) for 0 <= x < 8 from the line's table
+VAMP_DEV double taylor_table_eval(const double* tab, double x) {
+    int i = (int)(x * 2.0);
+    i = i < TAB_NI - 1 ? i : TAB_NI - 1;
+    const double d = fma((double)i, -CORE_H, x) - 0.5 * CORE_H;
+    const double* a = tab + i * TAB_NT;
+    double r = a[TAB_NT - 1];
+#pragma unroll
+    for (int n = TAB_NT - 2; n >= 0; --n) r = fma(r, d, a[n]);
+    return r;
+}
+
 // Per-point evaluator (k_model, k_wofz, host tests).  x >= 0, y >= 0; returns sqrt(pi) H.
 VAMP_DEV double voigt_Hs(double x, double y, const double* dtab, double pole, double hy) {
     const double r2 = fma(x, x, y * y);
