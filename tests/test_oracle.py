@@ -110,6 +110,37 @@ def test_device_arithmetic_host_build():
     assert np.max(np.abs(of[m] - wf[m]) / wf[m]) < 2e-4               # Humlicek's stated ~1e-4 + fp32
 
 
+def test_taylor_tables_host_build():
+    """Per-line Taylor tables of the near-axis zone (voigt_math.hpp, used by the 4-wavefront
+    workgroup kernels): centre values (real and imaginary part of sqrt(pi) w) and table
+    evaluations against mpmath at 40 digits."""
+    import mpmath as mp
+    so = os.path.join(ROOT, "tests", "host", "libvoigt_host.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = C.CDLL(so)
+    mp.mp.dps = 40
+    ys = np.array([1e-12, 1e-6, 0.01, 0.3, 1.0, 4.4, 4.6, 7.9])
+    idx = np.tile(np.arange(16, dtype=np.int32), len(ys))
+    yy = np.repeat(ys, 16)
+    re, im = np.empty(len(yy)), np.empty(len(yy))
+    lib.core_centre_host(C.c_int64(len(yy)), _dp(idx), _dp(yy), _dp(re), _dp(im))
+    for i, (k, y) in enumerate(zip(idx, yy)):
+        z = mp.mpc((int(k) + 0.5) / 2, float(y))
+        w = mp.sqrt(mp.pi) * mp.erfc(-1j * z) * mp.exp(-z * z)
+        assert abs(re[i] - float(w.real)) < 5e-16 and abs(im[i] - float(w.imag)) < 5e-16, (k, y)
+    rng = np.random.default_rng(1)
+    for y in (1e-4, 0.04, 0.3, 1.0, 3.0, 7.0):
+        x = np.sort(rng.uniform(0, np.sqrt(64 - y * y) - 1e-9, 300))
+        x[0], x[-1] = 0.0, np.sqrt(64 - y * y) - 1e-9
+        out = np.empty_like(x)
+        lib.voigt_H_table_host(C.c_int64(len(x)), _dp(x), _dp(np.full_like(x, y)), _dp(out))
+        ref = np.array([float(mp.re(mp.erfc(-1j * mp.mpc(a, y)) * mp.exp(-mp.mpc(a, y) ** 2))) for a in x])
+        err = np.abs(out - ref)
+        assert err.max() < 4e-16 and (err / ref).max() < 3e-14, y
+
+
 # ---- log-posterior -----------------------------------------------------------------------
 def _region_of(g, name):
     K = int(name.split("_K")[1].split("_")[0])

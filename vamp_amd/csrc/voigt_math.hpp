@@ -329,7 +329,7 @@ VAMP_DEV double voigt_core(double x, double y, const double* dtab, double pole, 
 //     Ws = sqrt(pi) w,  Ws' = -2 z Ws + 2i,  c_0 = Ws(z_i),  c_1 = -2 z_i c_0 + 2i,
 //     c_{n+1} = -2 (z_i c_n + c_{n-1}) / (n + 1),      sqrt(pi) H(x_i + d, y) = sum_n Re(c_n) d^n
 // (d real, |d| <= 1/4).  Measured against 40-digit references for y from 1e-12 to 8: absolute
-// error <= 2e-16, relative <= 2e-14 (tools/gen_voigt_tables.py --check-taylor).  One evaluation is
+// error <= 2e-16, relative <= 2e-14 (tests/test_oracle.py::test_taylor_tables_host_build).  One evaluation is
 // TAB_NT - 1 fused multiply-adds on coefficients read from LDS, against ~180 issue slots for the
 // rule itself; a table costs one rule evaluation (real and imaginary part) per interval.
 constexpr int TAB_NI = 16;            // intervals: [i/2, (i+1)/2)
