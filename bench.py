@@ -193,7 +193,7 @@ def main():
     # all-gather and the chain record are then ordered with the kernels without host syncs
     ens = ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange="nccl" if dist is not None else "none",
                           torch_device=torch.device("cuda", local_rank), torch_state=True, exchange_single_rank=args.force_dist)
-    own = ens.own_end - ens.own_begin
+    own = ens.own_count
 
     # chain storage (device resident): each rank records its own rows every step
     chain = None
@@ -208,7 +208,10 @@ def main():
 
     def record(i):
         if chain is not None:
-            chain[i].copy_(ens._own, non_blocking=True)      # D2D on the stream the kernels run on
+            off = 0
+            for rows in ens._own:                            # D2D on the stream the kernels run on
+                chain[i, off:off + rows.shape[0]].copy_(rows, non_blocking=True)
+                off += rows.shape[0]
 
     ens.step(args.warmup)
     sync_all()
@@ -229,13 +232,13 @@ def main():
 
     # sanity: the ensemble is alive (some proposals accepted, lnprob finite)
     _, lnp, nacc, _ = ctx.get_state()
-    acc_frac = float(nacc[ens.own_begin:ens.own_end].mean()) / max(1, args.steps + args.warmup)
-    finite_frac = float(np.isfinite(lnp[ens.own_begin:ens.own_end]).mean())
+    acc_frac = float(nacc[ens.own_mask].mean()) / max(1, args.steps + args.warmup)
+    finite_frac = float(np.isfinite(lnp[ens.own_mask]).mean())
 
     if rank == 0:
         value = W * args.steps / dt
         b_alg = algorithmic_bytes_per_walker_step(P, D, 8 if args.dtype == "f64" else 4)
-        per_launch_units = own // 2                     # walker-steps of one half-step launch on this rank
+        per_launch_units = own // (2 * ens.parts)       # walker-steps of one half-step launch on this rank
         avg_ms = k_ms / max(1, k_n)
         traffic = None
         try:      # HBM bytes per launch from the committed PMC run of this same command (tools/pmc.sh)

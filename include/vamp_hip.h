@@ -130,6 +130,14 @@ int vamp_sampler_init(vamp_ctx* ctx, int64_t W, const double* theta0, uint64_t s
  * (walker-parallel runs of ONE region over several devices).  After each half-step the host
  * all-gathers the walker rows [own_begin, own_end) of the state (RCCL via torch.distributed). */
 int vamp_sampler_set_shard(vamp_ctx* ctx, int rank, int world, int64_t* own_begin, int64_t* own_end);
+/* The same with this rank's share cut into `parts` pieces that are stepped and exchanged one
+ * after the other, so that the all-gather of piece p overlaps the kernel of piece p + 1.  The
+ * ensemble is first cut into `parts` equal row ranges, each of those into `world` shards: piece p
+ * of every rank lies in row range p, which makes its all-gather an in-place gather into one
+ * contiguous slab.  own_begin / own_end: arrays of `parts` row bounds.  Needs
+ * W / split_block to be a multiple of world * parts. */
+int vamp_sampler_set_shard_parts(vamp_ctx* ctx, int rank, int world, int parts, int64_t* own_begin,
+                                 int64_t* own_end);
 /* Use caller-owned device memory for the walker state (X[total_theta] and lnp[total_walkers],
  * both double), e.g. torch tensors that take part in collectives.  Call before sampler_init. */
 int vamp_sampler_bind_state(vamp_ctx* ctx, void* X_dev, void* lnp_dev);
@@ -138,6 +146,9 @@ int vamp_sampler_state_ptrs(vamp_ctx* ctx, void** X_dev, void** lnp_dev, int64_t
 /* one half-step (half = 0 red moves, 1 blue moves), asynchronous on the ctx stream; the step
  * counter advances after half 1 */
 int vamp_sampler_half_step(vamp_ctx* ctx, int half);
+/* piece `part` of this rank's share only (vamp_sampler_set_shard_parts); the step counter
+ * advances after the last piece of half 1.  vamp_sampler_half_step runs all pieces. */
+int vamp_sampler_half_step_part(vamp_ctx* ctx, int half, int part);
 /* same with every draw supplied by the host (deterministic-parity hook, single region):
  * active_idx[n], partner_idx[n] walker ids, zz[n] stretch factors, logu[n] = log(u2) */
 int vamp_sampler_half_step_ext(vamp_ctx* ctx, int region, int64_t n, const int32_t* active_idx,

@@ -42,6 +42,23 @@ class OracleBackend:
         self.slot_end = (rank + 1) * cpr * (self.block // 2)
         return rank * cpr * self.block, (rank + 1) * cpr * self.block
 
+    def sampler_set_shard_parts(self, rank, world, parts):
+        chunks = self.W // self.block
+        assert chunks % (world * parts) == 0
+        cpp = chunks // (world * parts)
+        hb = self.block // 2
+        self.part_slots = [((p * (chunks // parts) + rank * cpp) * hb, (p * (chunks // parts) + (rank + 1) * cpp) * hb)
+                           for p in range(parts)]
+        self.slot_begin, self.slot_end = self.part_slots[0]
+        return [(2 * b, 2 * e) for b, e in self.part_slots]
+
+    def half_step_part(self, half, part):
+        self.slot_begin, self.slot_end = self.part_slots[part]
+        step = self.step
+        self.half_step(half)
+        if half == 1 and part != len(self.part_slots) - 1:
+            self.step = step              # the counter advances after the last piece
+
     def half_step(self, half):
         red, blue = vo.split_tables(self.seed, self.step, self.W, self.block)
         act, comp = (red, blue) if half == 0 else (blue, red)
@@ -83,7 +100,7 @@ def _case():
     return region, X0
 
 
-def _worker(rank, world, port, use_gpu, out_dir):
+def _worker(rank, world, port, use_gpu, out_dir, parts=1, block=8):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -97,8 +114,8 @@ def _worker(rank, world, port, use_gpu, out_dir):
         backend.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
     else:
         backend = OracleBackend(region)
-    ens = ShardedEnsemble(backend, X0, seed=4242, split_block=8, dist=dist, exchange="gloo_host")
-    assert ens.own_end - ens.own_begin == X0.shape[0] // world
+    ens = ShardedEnsemble(backend, X0, seed=4242, split_block=block, dist=dist, exchange="gloo_host", parts=parts)
+    assert ens.own_count == X0.shape[0] // world and len(ens.own_ranges) == parts
     ens.step(6)
     X, lnp, nacc = ens.gather_state()
     if rank == 0:
@@ -107,10 +124,10 @@ def _worker(rank, world, port, use_gpu, out_dir):
     dist.destroy_process_group()
 
 
-def _run_ranks(world, use_gpu, tmp_path):
+def _run_ranks(world, use_gpu, tmp_path, parts=1, block=8):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, use_gpu, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, use_gpu, str(tmp_path), parts, block), nprocs=world, join=True)
     return np.load(os.path.join(str(tmp_path), "result.npz"))
 
 
@@ -123,6 +140,31 @@ def test_sharded_trajectory_is_rank_independent_cpu(world, tmp_path):
     assert np.array_equal(r["X"], chain[-1])            # bit-identical for every world size
     assert np.array_equal(r["lnp"], lchain[-1])
     assert np.array_equal(r["nacc"], nacc)
+
+
+@pytest.mark.parametrize("world,parts,block", [(2, 2, 8), (4, 2, 4), (2, 4, 4)])
+def test_piecewise_exchange_is_rank_independent_cpu(world, parts, block, tmp_path):
+    """A rank's share cut into pieces that are stepped and exchanged one after the other (the
+    layout behind the overlapped RCCL exchange): same trajectory as the unsharded sampler."""
+    region, X0 = _case()
+    fn = lambda q: vo.log_prob_batch_fast(region, q)
+    chain, lchain, nacc = vo.run_sampler(fn, X0, fn(X0), 6, seed=4242, block=block)
+    r = _run_ranks(world, False, tmp_path, parts=parts, block=block)
+    assert np.array_equal(r["X"], chain[-1])
+    assert np.array_equal(r["lnp"], lchain[-1])
+    assert np.array_equal(r["nacc"], nacc)
+
+
+def test_single_rank_pieces_match_run_sampler():
+    from vamp_amd.ensemble import ShardedEnsemble
+    region, X0 = _case()
+    ens = ShardedEnsemble(OracleBackend(region), X0, seed=4242, split_block=8, exchange="none", torch_state=False, parts=4)
+    assert ens.own_count == X0.shape[0] and len(ens.own_ranges) == 4
+    ens.step(6)
+    fn = lambda q: vo.log_prob_batch_fast(region, q)
+    chain, _, nacc = vo.run_sampler(fn, X0, fn(X0), 6, seed=4242, block=8)
+    X, lnp, na = ens.gather_state()
+    assert np.array_equal(X, chain[-1]) and np.array_equal(na, nacc)
 
 
 def test_single_rank_driver_matches_run_sampler():
@@ -150,11 +192,11 @@ def test_shard_needs_whole_chunks():
 
 @pytest.mark.gpu
 def test_two_ranks_share_one_gpu_real_kernels(tmp_path):
-    """HIP kernels under 2-way walker sharding (both ranks on device 0, host-staged gloo exchange)
-    reproduce the single-rank HIP trajectory and the oracle's."""
+    """HIP kernels under 2-way walker sharding, each share in two pieces (both ranks on device 0,
+    host-staged gloo exchange), reproduce the single-rank HIP trajectory and the oracle's."""
     import vamp_amd
     region, X0 = _case()
-    r = _run_ranks(2, True, tmp_path)
+    r = _run_ranks(2, True, tmp_path, parts=2)
     with vamp_amd.HipContext(device=0) as ctx:
         ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
         ctx.sampler_init(X0, seed=4242, split_block=8)

@@ -37,9 +37,11 @@ SIGNATURES = {
     "vamp_wofz_re": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
     "vamp_sampler_init": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_uint64, C.c_double, C.c_int32]),
     "vamp_sampler_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int64_p, c_int64_p]),
+    "vamp_sampler_set_shard_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int64_p, c_int64_p]),
     "vamp_sampler_bind_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "vamp_sampler_state_ptrs": (C.c_int, [C.c_void_p, c_void_pp, c_void_pp, c_int64_p, c_int64_p]),
     "vamp_sampler_half_step": (C.c_int, [C.c_void_p, C.c_int]),
+    "vamp_sampler_half_step_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "vamp_sampler_half_step_ext": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_int32_p, c_int32_p, c_double_p, c_double_p]),
     "vamp_sampler_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_double_p, c_double_p, c_int64_p, c_double_p]),
     "vamp_sampler_get_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int64_p, c_int64_p]),

@@ -1072,8 +1072,9 @@ struct vamp_ctx {
     double* lnp_d = nullptr;
     bool X_ext = false;
     long long* nacc_d = nullptr;
-    long long slot_begin = 0, slot_end = 0;
-    int shard_rank = 0, shard_world = 1;
+    long long slot_begin = 0, slot_end = 0;      // part 0 (the whole share when shard_parts == 1)
+    int shard_rank = 0, shard_world = 1, shard_parts = 1;
+    long long part_slots = 0, part_stride = 0;   // slots per part; distance between this rank's parts
     // grow-only scratch of vamp_lnprob (the MAP optimiser calls it thousands of times with W = 1)
     double *sc_th = nullptr, *sc_lp = nullptr, *sc_chi = nullptr;
     size_t sc_th_cap = 0, sc_w_cap = 0;
@@ -1136,7 +1137,7 @@ bool use_split(const vamp_ctx* c, long long n_walkers, bool small) {
     return c->packing == 0 && c->min_tiles >= 2 * PARTS && n_walkers < SPLIT_MAX_WALKERS;
 }
 
-int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n) {
+int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n, int part = 0) {
     SamplerDev S;
     S.regions = c->regions_d;
     S.n_regions = c->n_regions;
@@ -1147,9 +1148,9 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     S.X = c->X_d;
     S.lnp = c->lnp_d;
     S.n_accept = c->nacc_d;
-    S.slot_begin = c->slot_begin;
-    S.slot_end = c->slot_end;
-    const long long n = ext ? ext_n : (c->slot_end - c->slot_begin);
+    S.slot_begin = c->slot_begin + part * c->part_stride;
+    S.slot_end = c->shard_parts > 1 ? S.slot_begin + c->part_slots : c->slot_end;
+    const long long n = ext ? ext_n : (S.slot_end - S.slot_begin);
     if (n <= 0) return 0;
     // <16 lanes, 8 lines> packing needs every wave inside one region and one shard
     const int subs = PackSmall::SUBS;
@@ -1561,27 +1562,43 @@ int vamp_sampler_init(vamp_ctx* c, int64_t W, const double* theta0, uint64_t see
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->shard_rank = 0;
     c->shard_world = 1;
+    c->shard_parts = 1;
+    c->part_slots = c->part_stride = 0;
     c->slot_begin = 0;
     c->slot_end = c->total_walkers / 2;
     c->sampler_ready = true;
     return VAMP_OK;
 }
 
-int vamp_sampler_set_shard(vamp_ctx* c, int rank, int world, int64_t* own_begin, int64_t* own_end) {
+int vamp_sampler_set_shard_parts(vamp_ctx* c, int rank, int world, int parts, int64_t* own_begin, int64_t* own_end) {
     if (!c) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: ctx is NULL");
     if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_set_shard: call vamp_sampler_init first");
     if (world < 1 || rank < 0 || rank >= world) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: bad rank/world");
+    if (parts < 1 || parts > 64) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: parts must be in 1..64");
     if (c->n_regions != 1) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: walker sharding is for single-region contexts (shard regions across devices otherwise)");
     const long long chunks = c->W / c->split_block;
-    if (chunks % world) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: W/split_block must be a multiple of world");
-    const long long cpr = chunks / world;
+    if (chunks % ((long long)world * parts)) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: W/split_block must be a multiple of world * parts");
+    // the ensemble is cut into `parts` equal row ranges and each of those into `world` shards:
+    // part p of rank r = chunks [p * chunks/parts + r * cpp, ... + cpp)
+    const long long cpp = chunks / ((long long)world * parts);
+    const long long hb = c->split_block / 2;
     c->shard_rank = rank;
     c->shard_world = world;
-    c->slot_begin = rank * cpr * (c->split_block / 2);
-    c->slot_end = (rank + 1) * cpr * (c->split_block / 2);
-    if (own_begin) *own_begin = rank * cpr * c->split_block;
-    if (own_end) *own_end = (rank + 1) * cpr * c->split_block;
+    c->shard_parts = parts;
+    c->part_slots = cpp * hb;
+    c->part_stride = (chunks / parts) * hb;
+    c->slot_begin = rank * cpp * hb;
+    c->slot_end = c->slot_begin + c->part_slots;      // of part 0
+    for (int p = 0; p < parts; ++p) {
+        const long long first = p * (chunks / parts) + rank * cpp;
+        if (own_begin) own_begin[p] = first * c->split_block;
+        if (own_end) own_end[p] = (first + cpp) * c->split_block;
+    }
     return VAMP_OK;
+}
+
+int vamp_sampler_set_shard(vamp_ctx* c, int rank, int world, int64_t* own_begin, int64_t* own_end) {
+    return vamp_sampler_set_shard_parts(c, rank, world, 1, own_begin, own_end);
 }
 
 int vamp_sampler_state_ptrs(vamp_ctx* c, void** X_dev, void** lnp_dev, int64_t* total_theta, int64_t* total_walkers) {
@@ -1599,9 +1616,23 @@ int vamp_sampler_half_step(vamp_ctx* c, int half) {
     if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_half_step: call vamp_sampler_init first");
     if (half != 0 && half != 1) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step: half must be 0 or 1");
     HIP_TRY(hipSetDevice(c->device));
-    int rc = launch_half(c, half, false, 0, 0);
-    if (rc) return rc;
+    for (int p = 0; p < c->shard_parts; ++p) {
+        int rc = launch_half(c, half, false, 0, 0, p);
+        if (rc) return rc;
+    }
     if (half == 1) c->step += 1;
+    return VAMP_OK;
+}
+
+int vamp_sampler_half_step_part(vamp_ctx* c, int half, int part) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_part: ctx is NULL");
+    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_half_step_part: call vamp_sampler_init first");
+    if (half != 0 && half != 1) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_part: half must be 0 or 1");
+    if (part < 0 || part >= c->shard_parts) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_part: no such part");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = launch_half(c, half, false, 0, 0, part);
+    if (rc) return rc;
+    if (half == 1 && part == c->shard_parts - 1) c->step += 1;
     return VAMP_OK;
 }
 

@@ -182,6 +182,14 @@ class HipContext:
         _lib.check(self._lib.vamp_sampler_set_shard(self._h, rank, world, C.byref(b), C.byref(e)))
         return b.value, e.value
 
+    def sampler_set_shard_parts(self, rank, world, parts):
+        """Cut this rank's share into ``parts`` pieces (see vamp_sampler_set_shard_parts); returns
+        the list of (own_begin, own_end) row ranges, one per piece."""
+        b = (C.c_int64 * parts)()
+        e = (C.c_int64 * parts)()
+        _lib.check(self._lib.vamp_sampler_set_shard_parts(self._h, rank, world, parts, b, e))
+        return [(int(b[i]), int(e[i])) for i in range(parts)]
+
     def sampler_state_ptrs(self):
         X, L = C.c_void_p(), C.c_void_p()
         tt, tw = C.c_int64(0), C.c_int64(0)
@@ -190,6 +198,9 @@ class HipContext:
 
     def half_step(self, half):
         _lib.check(self._lib.vamp_sampler_half_step(self._h, int(half)))
+
+    def half_step_part(self, half, part):
+        _lib.check(self._lib.vamp_sampler_half_step_part(self._h, int(half), int(part)))
 
     def half_step_ext(self, active, partner, zz, logu, region=0):
         a = np.ascontiguousarray(active, dtype=np.int32)
