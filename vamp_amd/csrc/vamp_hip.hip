@@ -95,7 +95,10 @@ struct LineRec {           // per (walker, component), lives in LDS
 // walkers to fill 256 CUs evenly (a shard of the headline ensemble on one of 8 GPUs is 4096
 // walkers per half-step = 1.3 wavefronts per SIMD slot; the drain at the end of a launch costs
 // about half a wavefront lifetime).  The group shares one set of line records and tables.
-constexpr int PARTS = 4;
+#ifndef VAMP_PARTS
+#define VAMP_PARTS 4
+#endif
+constexpr int PARTS = VAMP_PARTS;
 template <int LPW_, int KCAP_, bool TAIL_, int WPB_, bool SPLIT_ = false>
 struct Pack {
     static constexpr int LPW = LPW_, KCAP = KCAP_, SUBS = 64 / LPW_;
@@ -1161,7 +1164,7 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     const bool split = use_split(c, n, small);
     const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : split ? 1 : PackWide::WALKERS_PER_BLOCK;
     const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
-    const unsigned threads = small ? PackSmall::THREADS : PackWide::THREADS;
+    const unsigned threads = small ? PackSmall::THREADS : split ? PackSplit::THREADS : PackWide::THREADS;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev.size()) {
@@ -1425,7 +1428,7 @@ int vamp_lnprob(vamp_ctx* c, int region, int64_t W, const double* theta, double*
     const bool split = use_split(c, W, small);
     const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : split ? 1 : PackWide::WALKERS_PER_BLOCK;
     const unsigned grid = (unsigned)((W + per_block - 1) / per_block);
-    const unsigned threads = small ? PackSmall::THREADS : PackWide::THREADS;
+    const unsigned threads = small ? PackSmall::THREADS : split ? PackSplit::THREADS : PackWide::THREADS;
     if (c->f32)
         VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, region,
                                                   c->pix(), (long long)W, th_d, lp_d, ch_d));
@@ -1549,7 +1552,7 @@ int vamp_sampler_init(vamp_ctx* c, int64_t W, const double* theta0, uint64_t see
         const bool split = use_split(c, W, small);
         const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : split ? 1 : PackWide::WALKERS_PER_BLOCK;
         const unsigned grid = (unsigned)((W + per_block - 1) / per_block);
-        const unsigned threads = small ? PackSmall::THREADS : PackWide::THREADS;
+        const unsigned threads = small ? PackSmall::THREADS : split ? PackSplit::THREADS : PackWide::THREADS;
         double* nochi = nullptr;
         if (c->f32)
             VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, r,
