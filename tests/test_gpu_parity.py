@@ -366,3 +366,26 @@ def test_split_workgroup_matches_wave_per_walker(P):
         else:
             a, b = got[0][0], got[1][0]
             assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(a))) <= 1e-12
+
+
+def test_fp32_posterior_means_agree_with_fp64():
+    """SURVEY 8d tolerance for config 5: posterior means of the fp32 / Humlicek-W4 run within 0.1
+    posterior standard deviations of the fp64 run.  A well-constrained synthetic region (256 px,
+    2 Voigt lines, sigma = 0.01: the posterior is narrow, so fp32 error would show), 512 walkers,
+    3000 steps thinned by 5, first third discarded; same seed and start (the two chains decorrelate
+    within a few steps, so the Monte Carlo error of each mean, ~0.02 sigma, is part of the budget)."""
+    import vamp_amd
+    from bench import make_workload
+    wl = make_workload(P=256, K=2, W=512, seed=4, nbz=False)
+    means, sds = [], []
+    for dtype in (vamp_amd.F64, vamp_amd.F32):
+        with vamp_amd.HipContext(device=0, dtype=dtype) as ctx:
+            ctx.set_regions(wl["x"], wl["flux"], wl["noise"], 2, mode=vo.MODE_VOIGT4)
+            ctx.sampler_init(wl["theta0"], seed=77)
+            res = ctx.run(3000, thin=5)
+        ch = res["chain"][200:].reshape(-1, 8)
+        assert np.isfinite(ch).all()
+        means.append(ch.mean(0))
+        sds.append(ch.std(0))
+    assert np.all(np.abs(means[0] - means[1]) <= 0.1 * sds[0]), (means, sds)
+    assert np.allclose(sds[0], sds[1], rtol=0.15)
