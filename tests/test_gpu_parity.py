@@ -263,6 +263,20 @@ def test_fp32_humlicek_path():
             assert np.array_equal(np.isfinite(want), np.isfinite(got)), name
             rel = np.abs(chi[fin] - wchi[fin]) / wchi[fin]
             assert np.median(rel) < 1e-4 and rel.max() < 1e-3, (name, rel.max())
+        # long regions: full tiles take the far-field interpolant (fp64 nodes, fp32 Clenshaw) for
+        # distant lines and W4 for near ones; with and without a ragged tail, both launch shapes
+        from bench import make_workload
+        for P, packing in ((2048, 0), (2048, 64), (3000, 0), (1000, 0)):
+            wl = make_workload(P=P, K=6, W=64, seed=21, nbz=False)
+            ctx.set_packing(packing)
+            ctx.set_regions(wl["x"], wl["flux"], wl["noise"], 6, mode=vo.MODE_VOIGT4)
+            got, chi = ctx.lnprob(wl["theta0"], return_chi2=True)
+            r = vo.Region(x=wl["x"], flux=wl["flux"], noise=wl["noise"], n_comp=6, mode=vo.MODE_VOIGT4)
+            want, wchi = vo.log_prob_batch(r, wl["theta0"], return_chi2=True)
+            assert np.isfinite(want).all() and np.isfinite(got).all()
+            rel = np.abs(chi - wchi) / wchi
+            assert np.median(rel) < 1e-4 and rel.max() < 1e-3, (P, packing, rel.max())
+        ctx.set_packing(0)
     finally:
         ctx.close()
 

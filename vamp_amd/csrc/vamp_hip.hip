@@ -500,6 +500,76 @@ __device__ __forceinline__ void ff_eval4(const double (&Xin)[4], const double (&
     }
 }
 
+// far-field steps shared by the fp64 and the fp32 sweep.  All wave-uniform in control flow.
+// (a) classification of all lines at once: far = centre >= FF_DIST half-widths beyond the tile's
+//     edge and the whole tile outside |z|^2 < 64 of that line; compacted list -> Sx.farlist
+__device__ __forceinline__ unsigned long long ff_classify(TileScratch& Sx, int K, int lane, double my_c, double my_w8,
+                                                          double mid, double half) {
+    const double dist = fabs(mid - my_c) - half;
+    const bool my_far = lane < K && dist >= FF_DIST * half && dist >= my_w8;
+    const unsigned long long farmask = __ballot(my_far);
+    if (my_far) Sx.farlist[__builtin_popcountll(farmask & ((1ull << lane) - 1ull))] = lane;
+    return farmask;
+}
+// (b) optical depth of the far lines at the tile's Chebyshev nodes -> Chebyshev coefficients in Sx.ffval
+template <int KCAP>
+__device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
+                                                int lane, int nfar, double mid, double half) {
+    const int node = lane & (FF_NODES - 1), grp = lane >> 4;
+    const double tnode = dct[FF_NODES * FF_NODES + node];          // cos(pi (node + 1/2) / 16)
+    __builtin_amdgcn_wave_barrier();
+    // 1. lane = (slot group, node), four lines per lane (line q = 4 t + group of the compacted far list)
+    const double xnode = fma(half, tnode, mid);
+    double Xn[4], yn[4], an[4], Hn[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int q = 4 * t + grp;
+        const int k = Sx.farlist[q < nfar ? q : nfar - 1];
+        Xn[t] = fabs(xnode - L.line[k].c) * L.line[k].s;
+        yn[t] = L.line[k].y;
+        an[t] = q < nfar ? L.line[k].amp : 0.0;
+    }
+    ff_eval4(Xn, yn, Hn);
+    double fs = fma(an[0], Hn[0], an[1] * Hn[1]) + fma(an[2], Hn[2], an[3] * Hn[3]);
+    fs += __shfl_xor(fs, 16, 64);
+    fs += __shfl_xor(fs, 32, 64);
+    // 2. c_m = (2/16) sum_j f_j cos(m pi (j + 1/2) / 16); lane m owns row m
+    if (lane < FF_NODES) Sx.ffval[lane] = fs;
+    __builtin_amdgcn_wave_barrier();
+    double cm = 0.0;
+#pragma unroll
+    for (int j = 0; j < FF_NODES; ++j) cm = fma(dct[j * FF_NODES + node], Sx.ffval[j], cm);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < FF_NODES) Sx.ffval[lane] = cm;
+    __builtin_amdgcn_wave_barrier();
+}
+// (c) Clenshaw at the tile's pixels, added to tau (in the pixel arithmetic type)
+template <class real, int T>
+__device__ __forceinline__ void ff_clenshaw(const TileScratch& Sx, const real (&xi)[T], double mid, double half, real (&tau)[T]) {
+    const real inv_half = (real)(1.0 / half), rmid = (real)mid;
+    real tt2[T], b1[T], b2[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        tt2[t] = (real)2 * ((xi[t] - rmid) * inv_half);
+        b1[t] = (real)0;
+        b2[t] = (real)0;
+    }
+#pragma unroll
+    for (int m = FF_NODES - 1; m >= 1; --m) {
+        const real c = (real)Sx.ffval[m];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const real b0 = fma(tt2[t], b1[t], c - b2[t]);
+            b2[t] = b1[t];
+            b1[t] = b0;
+        }
+    }
+    const real c0h = (real)(0.5 * Sx.ffval[0]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) tau[t] += fma((real)0.5 * tt2[t], b1[t], c0h - b2[t]);
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int MODE, class PK, bool TAB>
 __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
                                                const double* __restrict__ x, const double* __restrict__ f,
@@ -508,8 +578,6 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
     constexpr int T = TPIX;
     static_assert(PK::LPW == 64 && PK::KCAP <= 16, "far-field tiles: one walker per wavefront, <= 16 lines");
     const int K = R.K;
-    const int node = lane & (FF_NODES - 1), grp = lane >> 4;
-    const double tnode = dct[FF_NODES * FF_NODES + node];          // cos(pi (node + 1/2) / 16)
     // lane k < K classifies line k; w8 = half-width of |z|^2 < 64 around the line centre, in x units
     const int kk = lane < K ? lane : 0;
     const double my_c = L.line[kk].c;
@@ -524,13 +592,8 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
         // tile geometry (wave-uniform)
         const double x_lo = x[base], x_hi = x[base + 64 * T - 1];
         const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * (x_hi - x_lo);
-        // all lines classified at once: far = centre >= FF_DIST half-widths beyond the tile's edge and
-        // the whole tile outside |z|^2 < 64 of that line
-        const double dist = fabs(mid - my_c) - half;
-        const bool my_far = lane < K && dist >= FF_DIST * half && dist >= my_w8;
-        const unsigned long long farmask = __ballot(my_far);
+        const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, mid, half);
         const int nfar = __builtin_popcountll(farmask);
-        if (my_far) Sx.farlist[__builtin_popcountll(farmask & ((1ull << lane) - 1ull))] = lane;
         for (int k = 0; k < K; ++k) {
             if ((farmask >> k) & 1ull) continue;
             const LineRec ln = L.line[k];
@@ -542,55 +605,8 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
             for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
         }
         if (nfar > 0) {
-            __builtin_amdgcn_wave_barrier();
-            // 1. optical depth of the far lines at the tile's Chebyshev nodes: lane = (slot group, node),
-            //    four lines per lane (line q = 4 t + group of the compacted far list)
-            const double xnode = fma(half, tnode, mid);
-            double Xn[4], yn[4], an[4], Hn[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int q = 4 * t + grp;
-                const int k = Sx.farlist[q < nfar ? q : nfar - 1];
-                Xn[t] = fabs(xnode - L.line[k].c) * L.line[k].s;
-                yn[t] = L.line[k].y;
-                an[t] = q < nfar ? L.line[k].amp : 0.0;
-            }
-            ff_eval4(Xn, yn, Hn);
-            double fs = fma(an[0], Hn[0], an[1] * Hn[1]) + fma(an[2], Hn[2], an[3] * Hn[3]);
-            fs += __shfl_xor(fs, 16, 64);
-            fs += __shfl_xor(fs, 32, 64);
-            // 2. Chebyshev coefficients: c_m = (2/16) sum_j f_j cos(m pi (j + 1/2) / 16); lane m owns row m
-            if (lane < FF_NODES) Sx.ffval[lane] = fs;
-            __builtin_amdgcn_wave_barrier();
-            double cm = 0.0;
-#pragma unroll
-            for (int j = 0; j < FF_NODES; ++j) cm = fma(dct[j * FF_NODES + node], Sx.ffval[j], cm);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < FF_NODES) Sx.ffval[lane] = cm;
-            __builtin_amdgcn_wave_barrier();
-            // 3. Clenshaw at the tile's pixels
-            const double inv_half = 1.0 / half;
-            double tt2[T], b1[T], b2[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                tt2[t] = 2.0 * ((xi[t] - mid) * inv_half);
-                b1[t] = 0.0;
-                b2[t] = 0.0;
-            }
-#pragma unroll
-            for (int m = FF_NODES - 1; m >= 1; --m) {
-                const double c = Sx.ffval[m];
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const double b0 = fma(tt2[t], b1[t], c - b2[t]);
-                    b2[t] = b1[t];
-                    b1[t] = b0;
-                }
-            }
-            const double c0h = 0.5 * Sx.ffval[0];
-#pragma unroll
-            for (int t = 0; t < T; ++t) tau[t] += fma(0.5 * tt2[t], b1[t], c0h - b2[t]);
-            __builtin_amdgcn_wave_barrier();
+            ff_coefficients(L, Sx, dct, lane, nfar, mid, half);
+            ff_clenshaw<double, T>(Sx, xi, mid, half, tau);
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -672,6 +688,55 @@ __device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const Walker
     }
 }
 
+// fp32 sweep of full tiles with the far field: near lines through W4 in fp32, all far lines through
+// the tile's interpolant -- node values and cosine transform in fp64 (one evaluation per lane,
+// same code as the fp64 path), Clenshaw per pixel in fp32.
+template <int MODE, class PK>
+__device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx,
+                                                   const double* __restrict__ dct, const float* __restrict__ x,
+                                                   const float* __restrict__ f, const float* __restrict__ wt, int lane,
+                                                   int base0, int base1, int stride, double& chi) {
+    constexpr int T = TPIX;
+    static_assert(PK::LPW == 64 && PK::KCAP <= 16 && MODE != VAMP_GAUSS3, "far-field tiles: one walker per wavefront, Voigt lines");
+    const int K = R.K;
+    const int kk = lane < K ? lane : 0;
+    const double my_c = L.line[kk].c;
+    const double my_w8 = sqrt(fmax(vamp::R2_CORE - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
+    for (int base = base0; base < base1; base += stride) {
+        float xi[T], tau[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            xi[t] = x[base + 64 * t + lane];
+            tau[t] = 0.0f;
+        }
+        const double x_lo = (double)x[base], x_hi = (double)x[base + 64 * T - 1];
+        const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * (x_hi - x_lo);
+        const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, mid, half);
+        const int nfar = __builtin_popcountll(farmask);
+        for (int k = 0; k < K; ++k) {
+            if ((farmask >> k) & 1ull) continue;
+            const float c = L.linef[k][0], sc = L.linef[k][1], y = L.linef[k][2], a = L.linef[k][3];
+            float X[T], H[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) X[t] = fabsf(xi[t] - c) * sc;
+            tile_w4<T>(y, X, H);
+#pragma unroll
+            for (int t = 0; t < T; ++t) tau[t] = fmaf(a, H[t], tau[t]);
+        }
+        if (nfar > 0) {
+            ff_coefficients(L, Sx, dct, lane, nfar, mid, half);
+            ff_clenshaw<float, T>(Sx, xi, mid, half, tau);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int i = base + 64 * t + lane;
+            const float m = __expf(-tau[t]);
+            const float r = (f[i] - m) * wt[i];
+            chi += (double)r * (double)r;
+        }
+    }
+}
+
 struct PixPtrs {
     const double* x; const double* f; const double* wt;       // fp64 copies
     const float* xf; const float* ff; const float* wtf;       // fp32 copies (may be null)
@@ -689,7 +754,9 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<
     constexpr bool TAB = use_tables<F32, MODE, PK>();
     if constexpr (F32) {
         const float* x = px.xf + R.pix_off; const float* f = px.ff + R.pix_off; const float* wt = px.wtf + R.pix_off;
-        if (TPIX > 1) sweep_range_f32<MODE, PK, TPIX>(R, L, x, f, wt, lane, base0, full, stride, chi);
+        if constexpr (VAMP_FARFIELD && PK::SUBS == 1 && MODE != VAMP_GAUSS3 && TPIX == 4)
+            sweep_range_f32_ff<MODE, PK>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi);
+        else if (TPIX > 1) sweep_range_f32<MODE, PK, TPIX>(R, L, x, f, wt, lane, base0, full, stride, chi);
         if constexpr (PK::TAIL || TPIX == 1)
             if (tail) sweep_range_f32<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, PK::LPW, chi);
     } else {
