@@ -594,8 +594,9 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
         const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * (x_hi - x_lo);
         const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, mid, half);
         const int nfar = __builtin_popcountll(farmask);
-        for (int k = 0; k < K; ++k) {
-            if ((farmask >> k) & 1ull) continue;
+        // near lines: walk the set bits of the complement of the far mask (1-3 of 16 on the headline)
+        for (unsigned long long near = ~farmask & ((1ull << K) - 1ull); near; near &= near - 1ull) {
+            const int k = __builtin_ctzll(near);
             const LineRec ln = L.line[k];
             double X[T], H[T];
 #pragma unroll
@@ -713,8 +714,8 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const Wal
         const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * (x_hi - x_lo);
         const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, mid, half);
         const int nfar = __builtin_popcountll(farmask);
-        for (int k = 0; k < K; ++k) {
-            if ((farmask >> k) & 1ull) continue;
+        for (unsigned long long near = ~farmask & ((1ull << K) - 1ull); near; near &= near - 1ull) {
+            const int k = __builtin_ctzll(near);
             const float c = L.linef[k][0], sc = L.linef[k][1], y = L.linef[k][2], a = L.linef[k][3];
             float X[T], H[T];
 #pragma unroll
