@@ -64,14 +64,15 @@ int vamp_ctx_destroy(vamp_ctx* ctx);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the ctx's own */
 int vamp_ctx_set_stream(vamp_ctx* ctx, void* hip_stream);
 int vamp_ctx_synchronize(vamp_ctx* ctx);
-/* Lanes that serve one walker: 64 (one walker per wavefront; long regions), 256 (one walker per
- * 4-wavefront workgroup, each wavefront sweeping every 4th 256-pixel tile: launches with too few
- * walkers to fill the GPU, e.g. one GPU's shard of a small ensemble), 16 (four walkers per
+/* Lanes that serve one walker: 64 (one walker per wavefront), 256 (one walker per 4-wavefront
+ * workgroup: each wavefront sweeps every 4th 256-pixel tile and, in fp64, the line cores are read
+ * from per-line Taylor tables shared by the workgroup; long regions), 16 (four walkers per
  * wavefront, <= 8 components per region; the 9..478-pixel regions of real spectra) or 0 = choose:
- * 16 when every region has <= 8 components and the mean region is <= 128 pixels; else 256 for
- * launches of fewer than 16384 walkers on regions of >= 2048 pixels; else 64.  Takes effect at
- * the next vamp_set_regions.  64 and 256 give bit-identical results (same summation order); 16
- * agrees with them to rounding. */
+ * 16 when every region has <= 8 components and the mean region is <= 128 pixels; else 256 when
+ * every region has >= 2048 pixels; else 64.  The choice never depends on the number of walkers
+ * in a launch, so a shard of an ensemble runs the arithmetic of the whole ensemble.  Takes
+ * effect at the next vamp_set_regions.  All shapes agree to rounding (fp32: 64 and 256 bit for
+ * bit). */
 int vamp_ctx_set_packing(vamp_ctx* ctx, int lanes_per_walker);
 
 /* Upload the data of n_regions independent absorption regions (replaces

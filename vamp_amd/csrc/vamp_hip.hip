@@ -8,14 +8,18 @@
 //   * the sampler loop of mcmc_fit / find_bic (vpfits.py:361-395, 420-425), by the stretch move
 //     of Goodman & Weare (2010) with emcee's red/blue semantics.
 //
-// Execution shape: ONE 64-lane wavefront per walker (4 walkers per 256-thread workgroup).
+// Execution shape (struct Pack): a walker is served by one 64-lane wavefront, by a quarter of one
+// (short regions), or by a 4-wavefront workgroup whose wavefronts take every 4th 256-pixel tile
+// (long regions: the headline).
 //   stage   lanes 0..K-1 turn the walker's parameters into per-line records in LDS
 //           (centroid, x-scale, damping y, tau scale, pole factor) and all lanes fill the per-line
-//           table 1/(u_n^2 + y^2) used by the near-axis Voigt rule; priors are summed here.
-//   sweep   lane l takes pixels l, l+64, ...: coalesced 512-byte reads of x / flux / 1/sigma
-//           (shared by every walker -> L2/MALL resident), tau = sum_k tau_k in registers,
-//           flux = exp(-tau), chi^2 partial per lane.
-//   reduce  xor-shuffle tree over the wavefront; lane 0 owns the result.
+//           table 1/(u_n^2 + y^2) of the near-axis Voigt rule; priors are summed here.  A
+//           workgroup then builds the Taylor tables of the line cores (struct LineTables).
+//   sweep   lane l takes pixels l, l+64, ... of a tile: coalesced 512-byte reads of x / flux /
+//           1/sigma (shared by every walker -> L2/MALL resident); near lines are evaluated per
+//           pixel, all distant lines of the tile through ONE Chebyshev interpolant (ff_*);
+//           tau in registers, flux = exp(-tau), chi^2 partial per lane.
+//   reduce  xor-shuffle tree over the wavefront (+ LDS across the workgroup); lane 0 owns the result.
 //   move    (sampler kernel) proposal q = c - (c - s) z is formed in LDS before `stage`, and the
 //           accept test / state update follow `reduce` in the same launch.
 // No MFMA (nothing here is a contraction), no atomics, no inter-workgroup communication.
@@ -89,7 +93,7 @@ struct LineRec {           // per (walker, component), lives in LDS
 // one walker cannot fill a wave and the per-walker fixed work (staging, draws, reduction) dominates.
 //
 // SPLIT: the full tiles of a region are dealt round-robin into PARTS classes and chi^2 is summed
-// class by class (so the result does not depend on the packing).  SPLIT = false: one wavefront
+// class by class (so the summation order does not depend on the packing).  SPLIT = false: one wavefront
 // sweeps all classes of its walker.  SPLIT = true: the workgroup serves ONE walker and wavefront j
 // sweeps class j -- four times as many, four times shorter wavefronts, for launches with too few
 // walkers to fill 256 CUs evenly (a shard of the headline ensemble on one of 8 GPUs is 4096
@@ -747,7 +751,7 @@ struct PixPtrs {
 // full tiles are dealt round-robin into PARTS classes, each class is summed over its tiles and
 // over the wave, and the class sums are added in class order -- by this wavefront (SPLIT = false)
 // or through `red` by the PARTS wavefronts of the workgroup (SPLIT = true, `part` = this wave's
-// class): both give the same bits.  The tail (pixels beyond the last full tile) belongs to class 0.
+// class): the same order of additions either way.  The tail (pixels beyond the last full tile) belongs to class 0.
 template <bool F32, int MODE, class PK>
 __device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
                                             const PixPtrs& px, int lane, int base0, int full, int stride, bool tail, double& chi,
@@ -1201,7 +1205,7 @@ int flush_timing(vamp_ctx* c) {
     return 0;
 }
 
-// one walker per 4-wave workgroup?  (same bits either way: see Pack)
+// one walker per 4-wave workgroup?
 bool use_split(const vamp_ctx* c, long long n_walkers, bool small) {
     if (small) return false;
     if (c->packing == 256) return true;
