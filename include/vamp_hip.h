@@ -101,6 +101,23 @@ int vamp_region_ndim(vamp_ctx* ctx, int region, int* ndim);
  * unweighted sum of squared residuals. */
 int vamp_lnprob(vamp_ctx* ctx, int region, int64_t W, const double* theta, double* lnprob,
                 double* chi2);
+/* The same for EVERY region in one launch: theta holds the regions' [W, D_r] blocks one after the
+ * other, lnprob (and chi2, may be NULL) are [n_regions, W].  Serves the simultaneous MAP searches
+ * of all regions of a spectrum (vpfits.py:352-358, 426 per region in the reference). */
+int vamp_lnprob_all(vamp_ctx* ctx, int64_t W, const double* theta, double* lnprob, double* chi2);
+/* Maximum a posteriori search for every region at once: replaces mc.MAP(model).fit(iterlim, tol)
+ * (vpfits.py:352-358, 426), i.e. scipy's Nelder-Mead `fmin` on -logp, one region after the other
+ * in the reference.  Same simplex rules, start simplex and stopping test as fmin (xtol, ftol,
+ * maxiter iterations, maxfun evaluations per region), so each region follows the path fmin would
+ * take alone, but an iteration of all regions is one launch.  theta0 / theta_best: the regions'
+ * D_r-vectors one after the other; active[n_regions] (may be NULL = all) selects the regions to
+ * search, the others are returned unchanged.  A region whose search ends worse than its start
+ * keeps the start.  lnprob_best[n_regions] and chi2_best (may be NULL) describe the returned
+ * points; iterations (may be NULL) receives the simplex updates carried out per region (fmin
+ * reports one more: it counts from 1, and like fmin the search stops at maxiter - 1 updates). */
+int vamp_map_all(vamp_ctx* ctx, const double* theta0, const uint8_t* active, int64_t maxiter,
+                 int64_t maxfun, double xtol, double ftol, double* theta_best, double* lnprob_best,
+                 double* chi2_best, int64_t* iterations);
 
 /* Per-component optical depths tau_comp[K, P] and model flux[P] for one parameter vector:
  * the `component_k` and `profile` deterministics (vpfits.py:254-260, 299-305, 334-336) whose

@@ -403,3 +403,42 @@ def test_fp32_posterior_means_agree_with_fp64():
         sds.append(ch.std(0))
     assert np.all(np.abs(means[0] - means[1]) <= 0.1 * sds[0]), (means, sds)
     assert np.allclose(sds[0], sds[1], rtol=0.15)
+
+
+def test_map_all_follows_scipy_fmin(hip_ctx):
+    """vamp_map_all (every region's Nelder-Mead search advanced together, one launch per
+    iteration) against scipy.optimize.fmin run region by region on the same device log-posterior:
+    same rules, same start simplex, same stopping test -> the same optimum and iteration count."""
+    from scipy.optimize import fmin
+    c = load_golden("lnprob_cases.npz")
+    names = ["H1215_r0_K1_m1_sd0", "H1215_r1_K4_m1_sd0", "CII1036_r1_K4_m1_sd0", "H1215_r2_K1_m1_sd0"]
+    if hip_ctx.packing_request == 256:
+        pytest.skip("short regions: same kernels as packing 64")
+    xs, fs, ns, Ks, starts = [], [], [], [], []
+    for name in names:
+        x, f, n, K, mode, sd, _ = _case(c, name)
+        th, lnp = c[name + "_theta"], c[name + "_lnprob"]
+        xs.append(x); fs.append(f); ns.append(n); Ks.append(K)
+        starts.append(th[np.nanargmax(np.where(np.isfinite(lnp), lnp, -np.inf))].copy())
+    hip_ctx.set_regions(xs, fs, ns, Ks, mode=vo.MODE_VOIGT4)
+    active = np.array([1, 1, 0, 1], dtype=np.uint8)
+    best, lnp, chi, its = hip_ctx.map_all(starts, iterlim=250, tol=1e-3, active=active)
+    assert np.array_equal(best[2], starts[2]) and its[2] == 0          # inactive: returned unchanged
+    for r in (0, 1, 3):
+        def neg(t, r=r):
+            v = hip_ctx.lnprob(t, region=r)[0]
+            return -v if np.isfinite(v) else 1e300
+        xopt, fopt, it, calls, flag = fmin(neg, starts[r], xtol=1e-3, ftol=1e-3, maxiter=250, maxfun=1000, disp=False,
+                                           full_output=True)
+        assert it == its[r] + 1, (r, it, its[r])          # fmin counts iterations from 1
+        assert np.allclose(best[r], xopt, rtol=1e-13, atol=0), (r, best[r], xopt)
+        assert np.isclose(lnp[r], -fopt, rtol=1e-13)
+        l1, c1 = hip_ctx.lnprob(best[r], region=r, return_chi2=True)
+        assert l1[0] == lnp[r] and c1[0] == chi[r]
+        assert lnp[r] >= hip_ctx.lnprob(starts[r], region=r)[0]
+    # lnprob_all = lnprob region by region
+    blocks = [np.stack([s, s * 1.01, s * 0.99]) for s in starts]
+    la, ca = hip_ctx.lnprob_all(blocks, return_chi2=True)
+    for r in range(4):
+        l1, c1 = hip_ctx.lnprob(blocks[r], region=r, return_chi2=True)
+        assert np.array_equal(la[r], l1) and np.array_equal(ca[r], c1, equal_nan=True)

@@ -32,6 +32,9 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),
     "vamp_region_ndim": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "vamp_lnprob": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    "vamp_lnprob_all": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    "vamp_map_all": (C.c_int, [C.c_void_p, c_double_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double, c_double_p,
+                     c_double_p, c_double_p, c_int64_p]),
     "vamp_model": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "vamp_line_records": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "vamp_wofz_re": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),

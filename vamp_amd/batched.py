@@ -68,7 +68,10 @@ def find_bic_batched(ctx, regions, ns, voigt=False, nwalkers=64, iterations=3000
         naccs = res["n_accept"] if R > 1 else [res["n_accept"]]
         for r, f in enumerate(cur):
             f._ingest_chain(chains[r], lnps[r], naccs[r], burn + keep, keep, res["seconds"])
-            f.map.fit(iterlim=iterations, tol=1e-3)
+        # the MAP polish of every region together: one launch per Nelder-Mead iteration
+        best, lnp_best, ssum_best, _ = ctx.map_all([f._map_start() for f in cur], iterlim=iterations, tol=1e-3)
+        for r, f in enumerate(cur):
+            f._map_finish(best[r], lnp_best[r], ssum_best[r], f.map)
             nu, flux, noise = regions[r]
             freedom = freedoms[r] if freedoms is not None else flux.size - 3 * ns[r]
             bics[r].append(f.map.BIC)

@@ -128,6 +128,44 @@ class HipContext:
         _lib.check(self._lib.vamp_lnprob(self._h, region, W, _dp(theta), _dp(out), _dp(chi)))
         return (out, chi) if return_chi2 else out
 
+    def lnprob_all(self, thetas, return_chi2=False):
+        """thetas: one [W, D_r] array per region (same W).  Returns lnprob [n_regions, W] (and
+        chi2) from a single launch over every region."""
+        blocks = [_f64(np.atleast_2d(t)) for t in thetas]
+        if len(blocks) != self.n_regions:
+            raise ValueError("one theta block per region is required")
+        W = blocks[0].shape[0]
+        for r, b in enumerate(blocks):
+            if b.shape != (W, self.ndims[r]):
+                raise ValueError(f"region {r}: theta block must be [{W}, {self.ndims[r]}]")
+        flat = np.concatenate([b.ravel() for b in blocks])
+        out = np.empty((self.n_regions, W))
+        chi = np.empty((self.n_regions, W)) if return_chi2 else None
+        _lib.check(self._lib.vamp_lnprob_all(self._h, W, _dp(flat), _dp(out), _dp(chi)))
+        return (out, chi) if return_chi2 else out
+
+    def map_all(self, starts, iterlim=1000, tol=1e-3, active=None):
+        """Nelder-Mead MAP search of every (active) region at once (vamp_map_all).  starts: one
+        D_r-vector per region.  Returns (best [list of D_r-vectors], lnprob [n_regions],
+        chi2 [n_regions], iterations [n_regions])."""
+        vecs = [_f64(np.ravel(t)) for t in starts]
+        if len(vecs) != self.n_regions or any(v.size != d for v, d in zip(vecs, self.ndims)):
+            raise ValueError("one start vector of the region's dimension per region is required")
+        flat = np.concatenate(vecs)
+        best = np.empty_like(flat)
+        lnp, chi = np.empty(self.n_regions), np.empty(self.n_regions)
+        its = np.zeros(self.n_regions, dtype=np.int64)
+        act = None
+        if active is not None:
+            act = np.ascontiguousarray(np.asarray(active, dtype=np.uint8))
+            if act.size != self.n_regions:
+                raise ValueError("active needs one flag per region")
+        _lib.check(self._lib.vamp_map_all(self._h, _dp(flat), None if act is None else act.ctypes.data_as(C.c_void_p),
+                                          int(iterlim), 4 * int(iterlim), float(tol), float(tol), _dp(best), _dp(lnp),
+                                          _dp(chi), its.ctypes.data_as(_lib.c_int64_p)))
+        offs = np.concatenate([[0], np.cumsum(self.ndims)])
+        return [best[offs[r]:offs[r + 1]].copy() for r in range(self.n_regions)], lnp, chi, its
+
     def model(self, theta1, region=0):
         theta1 = _f64(theta1).ravel()
         if theta1.size != self.ndims[region]:

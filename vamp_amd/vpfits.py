@@ -10,7 +10,7 @@ what sits underneath:
   (vpfits.py:239-260, 283-305, 334-341)                (csrc/vamp_hip.hip, k_lnprob / k_half_step)
   one-at-a-time Metropolis, mc.MCMC.sample             affine-invariant stretch move, W walkers
   (vpfits.py:379-393, 420-425)                         (vamp_sampler_*), counter-based RNG
-  mc.MAP.fit = scipy fmin on -logp                     scipy fmin (Nelder-Mead) on -logp, every
+  mc.MAP.fit = scipy fmin on -logp                     fmin's Nelder-Mead on -logp in the library, every
   (vpfits.py:357-358, 419-426)                         evaluation a device call, started from the
                                                        best walker
   PyMC nodes (.value), mcmc.trace / stats, map.BIC     light stand-ins with the same attributes
@@ -269,6 +269,9 @@ class VPfit():
     def _loglike(self, theta_dev):
         """log-likelihood of the observed flux (device chi^2 / SSR, host epilogue)"""
         lnp, s = self._ctx.lnprob(theta_dev, region=self._region, return_chi2=True)
+        return self._loglike_from_sum(theta_dev, lnp, s)
+
+    def _loglike_from_sum(self, theta_dev, lnp, s):
         th = np.atleast_2d(theta_dev)
         if self._sample_sd:
             t = 1.0 / th[:, -1] ** 2
@@ -283,28 +286,34 @@ class VPfit():
         self.map = _MAP(self)
         self.map.fit(iterlim=iterations, tol=1e-3)
 
-    def _run_map(self, iterlim, tol, mp):
-        from scipy.optimize import fmin
-        ctx, reg = self._ctx, self._region
-
-        def neg(th):
-            v = ctx.lnprob(th, region=reg)[0]
-            return -v if np.isfinite(v) else 1e300
-
-        start = self._theta_dev
-        if self._lnp_chain is not None:          # polish the best posterior sample of the ensemble
+    def _map_start(self):
+        """Start of the MAP search: the best posterior sample of the ensemble if there is one
+        (polish), else the current parameter values."""
+        if self._lnp_chain is not None:
             i = np.unravel_index(np.argmax(self._lnp_chain), self._lnp_chain.shape)
-            start = self._chain_dev[i[0], i[1]]
-        best = fmin(neg, start, xtol=tol, ftol=tol, maxiter=iterlim, maxfun=4 * iterlim, disp=False)
-        if neg(best) > neg(start):
-            best = start
+            return self._chain_dev[i[0], i[1]]
+        return self._theta_dev
+
+    def _map_finish(self, best, lnp_best, ssum_best, mp):
+        """Adopt the optimum and fill the MAP object (PyMC 2.3 definitions, see _MAP)."""
         self._set_values(best)
-        mp.logp_at_max = float(ctx.lnprob(best, region=reg)[0])
-        mp.lnL = float(self._loglike(best)[0])
+        mp.logp_at_max = float(lnp_best)
+        mp.lnL = float(self._loglike_from_sum(best, lnp_best, ssum_best))
         k, n = self._ndim, self._flux.size
         mp.len, mp.data_len = k, n
         mp.BIC = k * np.log(n) - 2.0 * mp.lnL
         mp.AIC = 2.0 * k - 2.0 * mp.lnL
+
+    def _run_map(self, iterlim, tol, mp):
+        """Nelder-Mead on -logp in the library (vamp_map_all: scipy fmin's rules, every candidate
+        point of an iteration in one launch); only this fit's region of a shared context moves."""
+        ctx, reg = self._ctx, self._region
+        starts = [np.zeros(d) for d in ctx.ndims]
+        starts[reg] = np.asarray(self._map_start(), dtype=np.float64)
+        active = np.zeros(ctx.n_regions, dtype=np.uint8)
+        active[reg] = 1
+        best, lnp, ssum, _ = ctx.map_all(starts, iterlim=iterlim, tol=tol, active=active)
+        self._map_finish(best[reg], lnp[reg], ssum[reg], mp)
 
     # -- MCMC --------------------------------------------------------------------------------
     def mcmc_fit(self, iterations=15000, burnin=100, thinning=15, step_method=None):
