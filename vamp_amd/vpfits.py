@@ -298,7 +298,7 @@ class VPfit():
         """Adopt the optimum and fill the MAP object (PyMC 2.3 definitions, see _MAP)."""
         self._set_values(best)
         mp.logp_at_max = float(lnp_best)
-        mp.lnL = float(self._loglike_from_sum(best, lnp_best, ssum_best))
+        mp.lnL = float(np.ravel(self._loglike_from_sum(best, lnp_best, ssum_best))[0])
         k, n = self._ndim, self._flux.size
         mp.len, mp.data_len = k, n
         mp.BIC = k * np.log(n) - 2.0 * mp.lnL
