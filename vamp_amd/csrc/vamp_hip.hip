@@ -38,6 +38,9 @@
 #include "../../include/vamp_hip.h"
 #include "voigt_math.hpp"
 
+#ifndef VAMP_EARLY_LOADS
+#define VAMP_EARLY_LOADS 1
+#endif
 namespace {
 
 constexpr int KMAX = VAMP_MAX_COMPONENTS;
@@ -610,15 +613,28 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
 #pragma unroll
             for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
         }
-        if (nfar > 0) {
-            ff_coefficients(L, Sx, dct, lane, nfar, mid, half);
-            ff_clenshaw<double, T>(Sx, xi, mid, half, tau);
-        }
+        // flux and weights of the tile are requested here, ahead of the Clenshaw recurrence and the
+        // exponentials that separate them from their use: left to itself the compiler sinks each
+        // load to its use and the wavefront sits through eight L2 round trips per tile
+        double fi[T], wi[T];
+        if (nfar > 0) ff_coefficients(L, Sx, dct, lane, nfar, mid, half);
+#if VAMP_EARLY_LOADS
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const int i = base + 64 * t + lane;
+            fi[t] = f[base + 64 * t + lane];
+            wi[t] = wt[base + 64 * t + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (nfar > 0) ff_clenshaw<double, T>(Sx, xi, mid, half, tau);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#if !VAMP_EARLY_LOADS
+            fi[t] = f[base + 64 * t + lane];
+            wi[t] = wt[base + 64 * t + lane];
+#endif
             const double m = vamp::exp_taylor(-tau[t]);
-            const double r = (f[i] - m) * wt[i];
+            const double r = (fi[t] - m) * wi[t];
             chi = fma(r, r, chi);
         }
     }
