@@ -442,3 +442,47 @@ def test_map_all_follows_scipy_fmin(hip_ctx):
     for r in range(4):
         l1, c1 = hip_ctx.lnprob(blocks[r], region=r, return_chi2=True)
         assert np.array_equal(la[r], l1) and np.array_equal(ca[r], c1, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_long_regions_match_oracle(hip_ctx, seed):
+    """Seeded random long regions (full tiles + ragged tail, 1-16 lines) with line widths and
+    dampings spread over decades -- lines far narrower than a pixel, lines broader than the region,
+    heavily damped lines, centres at the region's edge, crowded blends: every branch of the tile
+    code (far-field interpolant, Taylor tables, fractions, cap, near-axis rule in the tail)
+    against the oracle's scipy.wofz restatement."""
+    if hip_ctx.packing_request == 16:
+        pytest.skip("long regions: one walker per wavefront or workgroup")
+    rng = np.random.default_rng(1000 + seed)
+    worst = 0.0
+    for case in range(6):
+        P = int(rng.choice([512, 1300, 2048, 2500, 4096]))
+        K = int(rng.integers(1, 17))
+        x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+        if case % 3 == 2:
+            x = np.cumsum(rng.uniform(0.5, 1.5, P))            # uneven pixel spacing
+            x -= x.mean()
+        W = 8
+        th = np.empty((W, K, 4))
+        th[:, :, 0] = 10.0 ** rng.uniform(-2, 1.7, (W, K))                      # amplitude
+        th[:, :, 1] = rng.uniform(x[0], x[-1], (W, K))                          # centroid
+        th[:, :, 1][:, 0] = np.where(rng.random(W) < 0.5, x[0], x[-1])          # one line on the edge
+        th[:, :, 2] = 10.0 ** rng.uniform(-6, np.log10(0.4 * (x[-1] - x[0])), (W, K))   # L_fwhm
+        th[:, :, 3] = 10.0 ** rng.uniform(-1.3, np.log10(0.4 * (x[-1] - x[0])), (W, K))  # G_fwhm
+        if K >= 4:
+            th[:, 1:4, 1] = th[:, 1:2, 1] + rng.normal(0, 3.0, (W, 3))          # a crowded blend
+            th[:, 1:4, 1] = np.clip(th[:, 1:4, 1], x[0], x[-1])
+        th = th.reshape(W, 4 * K)
+        noise = np.full(P, 0.05)
+        flux = np.clip(1.0 + rng.normal(0, 0.05, P), 0, None)
+        hip_ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
+        r = vo.Region(x=x, flux=flux, noise=noise, n_comp=K, mode=vo.MODE_VOIGT4)
+        want = vo.log_prob_batch_fast(r, th)
+        got = hip_ctx.lnprob(th)
+        assert np.array_equal(np.isfinite(want), np.isfinite(got)), (seed, case)
+        fin = np.isfinite(want)
+        assert fin.any()
+        err = np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))
+        worst = max(worst, err.max())
+        assert err.max() <= 1e-9, (seed, case, P, K, err.max())
+    assert worst <= 1e-9
