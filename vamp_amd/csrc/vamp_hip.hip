@@ -462,48 +462,44 @@ __device__ __forceinline__ void ff_fill_table(double* dct) {
     __syncthreads();
 }
 
-// sqrt(pi) H at one point per slot for FOUR different lines per lane (x[t], y[t]); every point has
-// |z|^2 >= 64.  One branch for the wavefront, the deepest any of its 256 points needs; two
-// reciprocals for four evaluations.
+// sqrt(pi) H at one point per slot for different lines per lane (x[t], y[t]), two slots at a time;
+// every point has |z|^2 >= 64.  One branch for the wavefront per slot PAIR, the deepest any of its
+// 128 points needs, and one reciprocal per pair.  (The far list is ordered deep lines first, so the
+// second pair usually runs the cheapest fraction.)
 template <int M>
-__device__ __forceinline__ void ff_frac4(const double (&X)[4], const double (&y)[4], const double (&r2)[4], double (&H)[4]) {
-    double n[4], d[4];
+__device__ __forceinline__ void ff_frac2(const double (&X)[2], const double (&y)[2], const double (&r2)[2], double (&H)[2]) {
+    double n[2], d[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) vamp::voigt_jfrac_nd<M>(X[t], y[t], r2[t], n[t], d[t]);
-    const double ra = vamp::rcp_nr(d[0] * d[1]), rb = vamp::rcp_nr(d[2] * d[3]);
+    for (int t = 0; t < 2; ++t) vamp::voigt_jfrac_nd<M>(X[t], y[t], r2[t], n[t], d[t]);
+    const double ra = vamp::rcp_nr(d[0] * d[1]);
     H[0] = n[0] * (ra * d[1]);
     H[1] = n[1] * (ra * d[0]);
-    H[2] = n[2] * (rb * d[3]);
-    H[3] = n[3] * (rb * d[2]);
 }
 
-__device__ __forceinline__ void ff_eval4(const double (&Xin)[4], const double (&y)[4], double (&H)[4]) {
-    double X[4], r2[4];
-    double lo, hi, ymin;
+__device__ __forceinline__ void ff_eval2(const double (&Xin)[2], const double (&y)[2], double (&H)[2]) {
+    double X[2], r2[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 2; ++t) {
         X[t] = fmin(Xin[t], vamp::X_FAR);       // lanes hold different lines: always guard the promotion
         r2[t] = fma(X[t], X[t], y[t] * y[t]);
-        lo = t ? fmin(lo, r2[t]) : r2[0];
-        hi = t ? fmax(hi, Xin[t]) : Xin[0];
-        ymin = t ? fmin(ymin, y[t]) : y[0];
     }
+    const double lo = fmin(r2[0], r2[1]), hi = fmax(Xin[0], Xin[1]), ymin = fmin(y[0], y[1]);
     if (__any(lo < vamp::R2_M3)) {
-        if (__any(lo < vamp::R2_M4)) ff_frac4<6>(X, y, r2, H);
-        else ff_frac4<4>(X, y, r2, H);
+        if (__any(lo < vamp::R2_M4)) ff_frac2<6>(X, y, r2, H);
+        else ff_frac2<4>(X, y, r2, H);
     } else if (__any(lo < vamp::R2_M2)) {
-        ff_frac4<3>(X, y, r2, H);
+        ff_frac2<3>(X, y, r2, H);
     } else {
-        ff_frac4<2>(X, y, r2, H);               // valid (more than accurate) beyond 1e8 too, up to X_FAR
+        ff_frac2<2>(X, y, r2, H);               // valid (more than accurate) beyond 1e8 too, up to X_FAR
     }
     if (__any(hi > vamp::X_FAR)) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 2; ++t)
             if (Xin[t] > vamp::X_FAR) H[t] = vamp::voigt_far(Xin[t], y[t], fma(Xin[t], Xin[t], y[t] * y[t]));
     }
     if (__any(ymin < vamp::Y_TINY)) {           // the fractions miss e^{-x^2}; it matters for y < ~1e-11 near |z| = 8
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 2; ++t)
             if (y[t] < vamp::Y_TINY) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
     }
 }
@@ -511,12 +507,18 @@ __device__ __forceinline__ void ff_eval4(const double (&Xin)[4], const double (&
 // far-field steps shared by the fp64 and the fp32 sweep.  All wave-uniform in control flow.
 // (a) classification of all lines at once: far = centre >= FF_DIST half-widths beyond the tile's
 //     edge and the whole tile outside |z|^2 < 64 of that line; compacted list -> Sx.farlist
+//     (my_w25: half-width of |z|^2 < 625; far lines that reach into it at the tile's edge need the
+//     deep fractions and are listed first)
 __device__ __forceinline__ unsigned long long ff_classify(TileScratch& Sx, int K, int lane, double my_c, double my_w8,
-                                                          double mid, double half) {
+                                                          double my_w25, double mid, double half) {
     const double dist = fabs(mid - my_c) - half;
     const bool my_far = lane < K && dist >= FF_DIST * half && dist >= my_w8;
-    const unsigned long long farmask = __ballot(my_far);
-    if (my_far) Sx.farlist[__builtin_popcountll(farmask & ((1ull << lane) - 1ull))] = lane;
+    const bool my_deep = my_far && dist < my_w25;
+    const unsigned long long farmask = __ballot(my_far), deepmask = __ballot(my_deep);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (my_far)
+        Sx.farlist[my_deep ? __builtin_popcountll(deepmask & below)
+                           : __builtin_popcountll(deepmask) + __builtin_popcountll(farmask & ~deepmask & below)] = lane;
     return farmask;
 }
 // (b) optical depth of the far lines at the tile's Chebyshev nodes -> Chebyshev coefficients in Sx.ffval
@@ -528,7 +530,7 @@ __device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileSc
     __builtin_amdgcn_wave_barrier();
     // 1. lane = (slot group, node), four lines per lane (line q = 4 t + group of the compacted far list)
     const double xnode = fma(half, tnode, mid);
-    double Xn[4], yn[4], an[4], Hn[4];
+    double Xn[4], yn[4], an[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int q = 4 * t + grp;
@@ -537,8 +539,19 @@ __device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileSc
         yn[t] = L.line[k].y;
         an[t] = q < nfar ? L.line[k].amp : 0.0;
     }
-    ff_eval4(Xn, yn, Hn);
-    double fs = fma(an[0], Hn[0], an[1] * Hn[1]) + fma(an[2], Hn[2], an[3] * Hn[3]);
+    double fs;
+    {
+        const double Xa[2] = {Xn[0], Xn[1]}, ya[2] = {yn[0], yn[1]};
+        double Ha[2];
+        ff_eval2(Xa, ya, Ha);
+        fs = fma(an[0], Ha[0], an[1] * Ha[1]);
+    }
+    if (nfar > 8) {                               // list entries 8..15 (slots 2, 3)
+        const double Xb[2] = {Xn[2], Xn[3]}, yb[2] = {yn[2], yn[3]};
+        double Hb[2];
+        ff_eval2(Xb, yb, Hb);
+        fs += fma(an[2], Hb[0], an[3] * Hb[1]);
+    }
     fs += __shfl_xor(fs, 16, 64);
     fs += __shfl_xor(fs, 32, 64);
     // 2. c_m = (2/16) sum_j f_j cos(m pi (j + 1/2) / 16); lane m owns row m
@@ -590,6 +603,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
     const int kk = lane < K ? lane : 0;
     const double my_c = L.line[kk].c;
     const double my_w8 = sqrt(fmax(vamp::R2_CORE - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
+    const double my_w25 = sqrt(fmax(vamp::R2_M3 - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
     for (int base = base0; base < base1; base += stride) {
         double xi[T], tau[T];
 #pragma unroll
@@ -600,7 +614,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
         // tile geometry (wave-uniform)
         const double x_lo = x[base], x_hi = x[base + 64 * T - 1];
         const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * (x_hi - x_lo);
-        const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, mid, half);
+        const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
         // near lines: walk the set bits of the complement of the far mask (1-3 of 16 on the headline)
         for (unsigned long long near = ~farmask & ((1ull << K) - 1ull); near; near &= near - 1ull) {
@@ -724,6 +738,7 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const Wal
     const int kk = lane < K ? lane : 0;
     const double my_c = L.line[kk].c;
     const double my_w8 = sqrt(fmax(vamp::R2_CORE - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
+    const double my_w25 = sqrt(fmax(vamp::R2_M3 - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
     for (int base = base0; base < base1; base += stride) {
         float xi[T], tau[T];
 #pragma unroll
@@ -733,7 +748,7 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const Wal
         }
         const double x_lo = (double)x[base], x_hi = (double)x[base + 64 * T - 1];
         const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * (x_hi - x_lo);
-        const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, mid, half);
+        const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
         for (unsigned long long near = ~farmask & ((1ull << K) - 1ull); near; near &= near - 1ull) {
             const int k = __builtin_ctzll(near);
