@@ -79,7 +79,8 @@ int vamp_ctx_set_packing(vamp_ctx* ctx, int lanes_per_walker);
  * VPfit.initialise_model's capture of frequency/flux/noise, vpfits.py:310-349, and the prior
  * bounds of vpfits.py:249-252,292-297,320,326).
  *   pix_off[n_regions+1]  CSR offsets into x/flux/noise
- *   x                     abscissa (ascending inside a region; same units as the width params)
+ *   x                     abscissa, finite and strictly monotonic inside a region (either direction;
+ *                         anything else is VAMP_ERR_ARG); same units as the width params
  *   n_comp[n_regions]     components per region (<= VAMP_MAX_COMPONENTS)
  *   mode                  vamp_mode, one for all regions
  *   sample_sd             1 = reference likelihood with free precision sd~U(0,1) as the last

@@ -232,6 +232,13 @@ def test_error_behaviour(hip_ctx):
         hip_ctx.half_step_ext([0], [99], [1.0], [0.0])
     with pytest.raises(vamp_amd._lib.VampError):
         vamp_amd.HipContext(device=0, dtype=vamp_amd.F32, wofz_kind=0)
+    # the grid of a region must be strictly monotonic and finite
+    for bad in (np.r_[g["x"][:5], g["x"][3], g["x"][6:]], np.r_[g["x"][:4], np.nan, g["x"][5:]],
+                np.r_[g["x"][:4], g["x"][3], g["x"][5:]]):
+        with pytest.raises(vamp_amd._lib.VampError) as e:
+            hip_ctx.set_regions(bad, g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)
+        assert e.value.code == -1
+    hip_ctx.set_regions(g["x"], g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)
     # non-finite parameters are -inf, not errors
     th = g["X0"].copy()
     th[0, 0] = np.nan
@@ -486,3 +493,21 @@ def test_random_long_regions_match_oracle(hip_ctx, seed):
         worst = max(worst, err.max())
         assert err.max() <= 1e-9, (seed, case, P, K, err.max())
     assert worst <= 1e-9
+
+
+def test_descending_grid_long_region(hip_ctx):
+    """A region uploaded in descending coordinate order (the reference flips to ascending
+    frequency, vpspectrum.py:274-277, but the ABI takes either direction): same log-posterior as
+    the ascending upload and as the oracle, through the tile code of long regions."""
+    if hip_ctx.packing_request == 16:
+        pytest.skip("long region: one walker per wavefront or workgroup")
+    from bench import make_workload
+    wl = make_workload(P=2304, K=7, W=16, seed=31, nbz=False)
+    hip_ctx.set_regions(wl["x"], wl["flux"], wl["noise"], 7, mode=vo.MODE_VOIGT4)
+    up = hip_ctx.lnprob(wl["theta0"])
+    hip_ctx.set_regions(wl["x"][::-1].copy(), wl["flux"][::-1].copy(), wl["noise"][::-1].copy(), 7, mode=vo.MODE_VOIGT4)
+    down = hip_ctx.lnprob(wl["theta0"])
+    r = vo.Region(x=wl["x"], flux=wl["flux"], noise=wl["noise"], n_comp=7, mode=vo.MODE_VOIGT4)
+    want = vo.log_prob_batch_fast(r, wl["theta0"])
+    for got in (up, down):
+        assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) <= 1e-9

@@ -613,7 +613,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
         }
         // tile geometry (wave-uniform)
         const double x_lo = x[base], x_hi = x[base + 64 * T - 1];
-        const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * (x_hi - x_lo);
+        const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * fabs(x_hi - x_lo);
         const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
         // near lines: walk the set bits of the complement of the far mask (1-3 of 16 on the headline)
@@ -747,7 +747,7 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const Wal
             tau[t] = 0.0f;
         }
         const double x_lo = (double)x[base], x_hi = (double)x[base + 64 * T - 1];
-        const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * (x_hi - x_lo);
+        const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * fabs(x_hi - x_lo);
         const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
         for (unsigned long long near = ~farmask & ((1ull << K) - 1ull); near; near &= near - 1ull) {
@@ -1432,9 +1432,9 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
             d.c_hi = bounds[4 * r + 1];
             d.w_max = (mode == VAMP_GAUSS3) ? bounds[4 * r + 2] : bounds[4 * r + 3];
         } else {
-            d.c_lo = xr[0];                                  // vpfits.py:250
-            d.c_hi = xr[P - 1];
-            const double sigma_max = (xr[P - 1] - xr[0]) / 2.0;                       // vpfits.py:320
+            d.c_lo = std::min(xr[0], xr[P - 1]);             // vpfits.py:250 (the reference's grid ascends)
+            d.c_hi = std::max(xr[0], xr[P - 1]);
+            const double sigma_max = (d.c_hi - d.c_lo) / 2.0;                         // vpfits.py:320
             d.w_max = (mode == VAMP_GAUSS3) ? sigma_max : sigma_max * 2 * std::sqrt(2 * std::log(2.0));   // :326
         }
         if (!(d.c_hi > d.c_lo) || !(d.w_max > 0)) return fail(VAMP_ERR_ARG, "vamp_set_regions: empty prior range");
@@ -1455,8 +1455,17 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
             nc *= -0.5;
         }
         d.norm_const = nc;
+        // the tile code takes a tile's first and last pixel as its extent: the grid of a region must be
+        // strictly monotonic (either direction; the reference sorts to ascending frequency,
+        // vpspectrum.py:274-277) and finite
         double dxmax = 0.0;
-        for (long long i = 1; i < P; ++i) dxmax = std::max(dxmax, std::fabs(xr[i] - xr[i - 1]));
+        const bool up = xr[1] > xr[0];
+        for (long long i = 1; i < P; ++i) {
+            const double dx = xr[i] - xr[i - 1];
+            if (!std::isfinite(dx) || dx == 0.0 || (dx > 0.0) != up)
+                return fail(VAMP_ERR_ARG, "vamp_set_regions: x must be finite and strictly monotonic within a region");
+            dxmax = std::max(dxmax, std::fabs(dx));
+        }
         d.tile_span = 64.0 * TPIX * dxmax;
         R[r] = d;
     }
