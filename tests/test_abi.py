@@ -79,3 +79,27 @@ def test_default_split_block():
     assert vamp_amd.default_split_block(4096, world=8) == 512
     b = vamp_amd.default_split_block(16384, world=6 if False else 4)
     assert 16384 % b == 0 and b % 2 == 0 and (16384 // b) % 4 == 0
+
+
+def _build_c_client(tmp_path):
+    import subprocess
+    exe = os.path.join(str(tmp_path), "abi_client")
+    libdir = os.path.join(ROOT, "vamp_amd")
+    subprocess.check_call(["gcc", "-O1", "-std=c99", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "host", "abi_client.c"),
+                           "-L" + libdir, "-lvamp_hip", "-lm", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_c_client_compiles_and_links(tmp_path):
+    """include/vamp_hip.h is plain C99 and libvamp_hip.so links from gcc without Python or torch."""
+    assert os.path.exists(_build_c_client(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_client_runs(tmp_path):
+    """The plain-C client (tests/host/abi_client.c): log-posterior against its own closed form, a
+    short sampler run and the error path, through the C ABI only."""
+    import subprocess
+    out = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "abi_client ok" in out.stdout
