@@ -270,6 +270,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "bytes of HBM traffic per launch (PMC, separate passes)",
+                         "measured_hbm_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and k_n) else None,
                          "algorithmic_bytes_per_launch": per_launch_units * b_alg,
                          "kernel": "k_half_step", "avg_launch_ms": avg_ms, "launches": k_n,
                          "alg_bytes_per_walker_step": b_alg, "walker_steps_per_launch": per_launch_units},
