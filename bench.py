@@ -147,8 +147,8 @@ class _StdoutToStderr:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--walkers", type=int, default=65536)
     ap.add_argument("--pixels", type=int, default=16384)
     ap.add_argument("--components", type=int, default=16)
