@@ -511,3 +511,38 @@ def test_descending_grid_long_region(hip_ctx):
     want = vo.log_prob_batch_fast(r, wl["theta0"])
     for got in (up, down):
         assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) <= 1e-9
+
+
+def test_long_region_all_modes(hip_ctx):
+    """The long-region launch shapes in every parameterisation and likelihood form: Gaussian
+    components (no far field, tiles dealt to the wavefronts), Voigt with the reference's free
+    precision sd ~ U(0,1) as last dimension, and (N, b, z) -- log-posterior against the oracle and
+    a few stretch steps against the oracle's sampler."""
+    if hip_ctx.packing_request == 16:
+        pytest.skip("long regions: one walker per wavefront or workgroup")
+    from bench import make_workload
+    cases = []
+    wl = make_workload(P=2304, K=5, W=32, seed=41, nbz=False)
+    th4 = wl["theta0"].reshape(32, 5, 4)
+    thg = np.stack([th4[:, :, 0], th4[:, :, 1], th4[:, :, 3] / 2.3548200450309493], axis=2).reshape(32, 15)
+    cases.append(("gauss", dict(mode=vo.MODE_GAUSS3), wl, thg))
+    sd = np.random.default_rng(2).uniform(0.005, 0.05, (32, 1))
+    cases.append(("voigt+sd", dict(mode=vo.MODE_VOIGT4, sample_sd=True), wl, np.hstack([wl["theta0"], sd])))
+    wn = make_workload(P=2560, K=5, W=32, seed=43, nbz=True)
+    cases.append(("nbz", dict(mode=vo.MODE_NBZ3), wn, wn["theta0"]))
+    for name, kw, w, th in cases:
+        nbz = w["nbz"] if kw["mode"] == vo.MODE_NBZ3 else None
+        hip_ctx.set_regions(w["x"], w["flux"], w["noise"], 5, nbz=nbz, **kw)
+        r = vo.Region(x=w["x"], flux=w["flux"], noise=w["noise"], n_comp=5, **kw)
+        if nbz is not None:
+            r.l_fixed, r.line, r.x_origin, r.x_scale = [float(v) for v in nbz[0]]
+        want = vo.log_prob_batch_fast(r, th)
+        got = hip_ctx.lnprob(th)
+        assert np.isfinite(want).all(), name
+        assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) <= 1e-9, name
+        hip_ctx.sampler_init(th, seed=7, split_block=16)
+        res = hip_ctx.run(3)
+        fn = lambda q, r=r: vo.log_prob_batch_fast(r, q)
+        chain, _, nacc = vo.run_sampler(fn, th, want, 3, seed=7, block=16)
+        assert np.allclose(res["chain"], chain, rtol=1e-10, atol=1e-12), name
+        assert np.array_equal(res["n_accept"], nacc), name
