@@ -522,7 +522,9 @@ __device__ __forceinline__ unsigned long long ff_classify(TileScratch& Sx, int K
     return farmask;
 }
 // (b) optical depth of the far lines at the tile's Chebyshev nodes -> Chebyshev coefficients in Sx.ffval
-template <int KCAP>
+//     W4NODES (fp32 contexts): node values through Humlicek's W4 in fp32 -- every far point has
+//     |x| + y >= 8, so region II (or I, wave-uniform) applies; transform and coefficients stay fp64
+template <int KCAP, bool W4NODES = false>
 __device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
                                                 int lane, int nfar, double mid, double half) {
     const int node = lane & (FF_NODES - 1), grp = lane >> 4;
@@ -530,6 +532,39 @@ __device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileSc
     __builtin_amdgcn_wave_barrier();
     // 1. lane = (slot group, node), four lines per lane (line q = 4 t + group of the compacted far list)
     const double xnode = fma(half, tnode, mid);
+    if constexpr (W4NODES) {
+        const float xn = (float)xnode;
+        float X[4], yv[4], av[4], lo;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = 4 * t + grp;
+            const int k = Sx.farlist[q < nfar ? q : nfar - 1];
+            X[t] = fabsf(xn - L.linef[k][0]) * L.linef[k][1];
+            yv[t] = L.linef[k][2];
+            av[t] = q < nfar ? L.linef[k][3] : 0.0f;
+            lo = t ? fminf(lo, X[t] + yv[t]) : X[0] + yv[0];
+        }
+        float fsf = 0.0f;
+        if (!__any(!(lo >= 15.0f))) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fsf = fmaf(av[t], vamp::w4_region1(X[t], yv[t]), fsf);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fsf = fmaf(av[t], vamp::w4_region2(X[t], yv[t]), fsf);
+        }
+        double fs = (double)fsf;
+        fs += __shfl_xor(fs, 16, 64);
+        fs += __shfl_xor(fs, 32, 64);
+        if (lane < FF_NODES) Sx.ffval[lane] = fs;
+        __builtin_amdgcn_wave_barrier();
+        double cm = 0.0;
+#pragma unroll
+        for (int j = 0; j < FF_NODES; ++j) cm = fma(dct[j * FF_NODES + node], Sx.ffval[j], cm);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < FF_NODES) Sx.ffval[lane] = cm;
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
     double Xn[4], yn[4], an[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -761,7 +796,7 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const Wal
             for (int t = 0; t < T; ++t) tau[t] = fmaf(a, H[t], tau[t]);
         }
         if (nfar > 0) {
-            ff_coefficients(L, Sx, dct, lane, nfar, mid, half);
+            ff_coefficients<PK::KCAP, true>(L, Sx, dct, lane, nfar, mid, half);
             ff_clenshaw<float, T>(Sx, xi, mid, half, tau);
         }
 #pragma unroll
