@@ -546,3 +546,32 @@ def test_long_region_all_modes(hip_ctx):
         chain, _, nacc = vo.run_sampler(fn, th, want, 3, seed=7, block=16)
         assert np.allclose(res["chain"], chain, rtol=1e-10, atol=1e-12), name
         assert np.array_equal(res["n_accept"], nacc), name
+
+
+def test_long_region_symmetries(hip_ctx):
+    """Size-independent properties of the tile code on a 4096-pixel region (no CPU reference
+    needed): chi^2 is unchanged when the grid and the centroids are translated, when grid,
+    centroids and widths are scaled together, and when the spectrum is mirrored (a descending
+    grid).  Each transformation moves the tile boundaries relative to the lines, so the far /
+    near classification, the table intervals and the interpolation nodes all change."""
+    if hip_ctx.packing_request == 16:
+        pytest.skip("long region: one walker per wavefront or workgroup")
+    from bench import make_workload
+    wl = make_workload(P=4096, K=9, W=24, seed=77, nbz=False)
+    x, f, n, th = wl["x"], wl["flux"], wl["noise"], wl["theta0"].reshape(24, 9, 4)
+
+    def chi2(xg, fg, ng, t):
+        hip_ctx.set_regions(xg, fg, ng, 9, mode=vo.MODE_VOIGT4)
+        lnp, c = hip_ctx.lnprob(t.reshape(24, 36), return_chi2=True)
+        assert np.isfinite(lnp).all()
+        return c
+
+    base = chi2(x, f, n, th)
+    t = th.copy(); t[:, :, 1] += 137.3
+    assert np.allclose(chi2(x + 137.3, f, n, t), base, rtol=2e-11)
+    t = th.copy(); t[:, :, 1:] *= 0.37
+    assert np.allclose(chi2(x * 0.37, f, n, t), base, rtol=2e-11)
+    t = th.copy(); t[:, :, 1] *= -1.0
+    assert np.allclose(chi2(-x, f, n, t), base, rtol=2e-11)
+    t = th.copy(); t[:, :, 1] = -t[:, :, 1] + 5.5
+    assert np.allclose(chi2((-x + 5.5)[::-1].copy(), f[::-1].copy(), n[::-1].copy(), t), base, rtol=2e-11)
