@@ -97,6 +97,10 @@ def make_ref_statics():
 
 
 def make_simba():
+    # one of the reference's data files as it is (written by h5py: the real-file fixture of the
+    # minimal HDF5 reader / writer, tests/test_h5min.py)
+    import shutil
+    shutil.copyfile(os.path.join(REF, "data", "simba_H1215.h5"), os.path.join(HERE, "simba_H1215.h5"))
     out = {}
     for tag, fn in (("H1215", "simba_H1215.h5"), ("CII1036", "simba_CII1036.h5")):
         d = vo.read_simba_raw(os.path.join(REF, "data", fn))

@@ -57,30 +57,21 @@ def test_estimate_n_and_freedom_kats():
     assert ((ns == 1).sum(), ((ns >= 4) & (ns <= 8)).sum(), ((ns >= 9) & (ns <= 14)).sum()) == (361, 45, 15)
 
 
-def test_raw_hdf5_reader_and_text_reader(tmp_path):
-    """The simba demo files are HDF5 v0 with contiguous f8[1000] datasets at fixed offsets; the
-    reader must work without h5py.  A file with that layout is rebuilt from the fixture."""
-    from vamp_amd.vpspectrum import SIMBA_RAW_OFFSETS, read_spectrum_file
+def test_hdf5_reader_and_text_reader(tmp_path):
+    """Spectrum files: HDF5 without h5py (vamp_amd/h5min.py; here a copy of the reference's own
+    simba_H1215.h5) and the 4-column text form of q1422.cont."""
+    from vamp_amd.vpspectrum import read_spectrum_file
     g = load_golden("simba_spectra.npz")
-    buf = bytearray(60096)
-    buf[:8] = b"\x89HDF\r\n\x1a\n"
-    for key in ("wavelength", "flux", "noise"):
-        off = SIMBA_RAW_OFFSETS[key]
-        buf[off:off + 8000] = g["H1215_" + key].astype("<f8").tobytes()
-    p = tmp_path / "spectrum_0.h5"
-    p.write_bytes(bytes(buf))
-    try:
-        import h5py  # noqa: F401
-        pytest.skip("h5py present: the raw-layout path is not the one taken")
-    except ImportError:
-        pass
-    wl, fl, no = read_spectrum_file(str(p))
+    wl, fl, no = read_spectrum_file(os.path.join(ROOT, "tests", "golden", "simba_H1215.h5"))
     assert np.array_equal(wl, g["H1215_wavelength"]) and np.array_equal(fl, g["H1215_flux"]) and np.array_equal(no, g["H1215_noise"])
     t = tmp_path / "s.cont"
     np.savetxt(t, np.stack([wl[:50], np.zeros(50), fl[:50], no[:50]], 1), fmt="%.9f")
     wl2, fl2, no2 = read_spectrum_file(str(t))
     assert np.allclose(wl2, wl[:50], atol=1e-9) and np.allclose(fl2, fl[:50], atol=1e-9)
-    assert SIMBA_RAW_OFFSETS == vo.SIMBA_OFFSETS
+    # the byte offsets the oracle reads the simba files at (SURVEY 8d) are where the parser finds the datasets
+    buf = open(os.path.join(ROOT, "tests", "golden", "simba_H1215.h5"), "rb").read()
+    for key in ("wavelength", "flux", "noise"):
+        assert np.array_equal(np.frombuffer(buf, "<f8", 1000, vo.SIMBA_OFFSETS[key]), g["H1215_" + key])
 
 
 def test_physics_module_matches_reference_statics():
@@ -128,15 +119,10 @@ def test_region_fit_model_selection():
 def test_fit_spectrum_end_to_end_and_cli(tmp_path):
     """do_vamp on a spectrum file with the simba layout: detection -> region fits -> parameter
     harvest -> result files (vpspectrum.py:243-442, do_vamp.py:41-60)."""
-    from vamp_amd.vpspectrum import SIMBA_RAW_OFFSETS
+    from vamp_amd import h5min
     g = load_golden("simba_spectra.npz")
-    buf = bytearray(60096)
-    buf[:8] = b"\x89HDF\r\n\x1a\n"
-    for key in ("wavelength", "flux", "noise"):
-        off = SIMBA_RAW_OFFSETS[key]
-        buf[off:off + 8000] = g["CII1036_" + key].astype("<f8").tobytes()
     spec = tmp_path / "spectrum_7.h5"
-    spec.write_bytes(bytes(buf))
+    h5min.write(str(spec), {k: g["CII1036_" + k] for k in ("wavelength", "flux", "noise")})
     out = tmp_path / "out"
     env = dict(os.environ, PYTHONPATH=ROOT, MPLBACKEND="Agg")
     rc = subprocess.run([sys.executable, "-m", "vamp_amd.do_vamp", str(spec), "1036.3367", "--output_folder", str(out),
@@ -145,23 +131,21 @@ def test_fit_spectrum_end_to_end_and_cli(tmp_path):
     assert rc.returncode == 0, rc.stderr[-2000:]
     assert "Found 4 detection regions." in rc.stdout
     files = sorted(os.listdir(out))
-    ext = "h5" if any(f.endswith("params.h5") for f in files) else "npz"
-    assert f"spectrum_7_gauss_params.{ext}" in files and f"spectrum_7_gauss_flux_model.{ext}" in files
-    if ext == "npz":
-        p = np.load(out / "spectrum_7_gauss_params.npz")
-        assert set(p.files) == {"b", "b_std", "N", "N_std", "EW", "centers", "region_numbers"}
-        n = p["b"].size
-        assert n >= 4 and all(p[k].size == n for k in ("N", "b_std", "N_std", "EW", "centers", "region_numbers"))
-        assert np.all(p["b"] > 0) and np.all(p["N"] > 0)
-        assert np.all((p["centers"] > 1036.0) & (p["centers"] < 1057.0))       # Angstrom, inside the spectrum
-        fm = np.load(out / "spectrum_7_gauss_flux_model.npz")
-        assert fm["total"].shape == (1000,) and fm["chi_squared"].shape == (4,)
-        assert np.array_equal(fm["region_pixels"], g["CII1036_region_pixels"])
-        # outside the regions the model is the continuum
-        mask = np.ones(1000, bool)
-        for s, e in g["CII1036_region_pixels"]:
-            mask[s:e] = False
-        assert np.all(fm["total"][mask] == 1.0)
+    assert "spectrum_7_gauss_params.h5" in files and "spectrum_7_gauss_flux_model.h5" in files
+    p = h5min.read(str(out / "spectrum_7_gauss_params.h5"))
+    assert set(p) == {"b", "b_std", "N", "N_std", "EW", "centers", "region_numbers"}
+    n = p["b"].size
+    assert n >= 4 and all(p[k].size == n for k in ("N", "b_std", "N_std", "EW", "centers", "region_numbers"))
+    assert np.all(p["b"] > 0) and np.all(p["N"] > 0)
+    assert np.all((p["centers"] > 1036.0) & (p["centers"] < 1057.0))       # Angstrom, inside the spectrum
+    fm = h5min.read(str(out / "spectrum_7_gauss_flux_model.h5"))
+    assert fm["total"].shape == (1000,) and fm["chi_squared"].shape == (4,)
+    assert np.array_equal(fm["region_pixels"], g["CII1036_region_pixels"])
+    # outside the regions the model is the continuum
+    mask = np.ones(1000, bool)
+    for s, e in g["CII1036_region_pixels"]:
+        mask[s:e] = False
+    assert np.all(fm["total"][mask] == 1.0)
 
 
 @pytest.mark.gpu

@@ -5,8 +5,8 @@ hot path), harvest physical parameters, write the result files.
 Host-side numpy, as in the reference (it runs once per spectrum).  Intended behaviour of the main
 path is reproduced; the reference's defects on rarely taken branches are not:
 undefined names in ``split_difficult_region`` (vpspectrum.py:190,198,225) and in the forced
-component increase (:309,316), and the missing h5py dependency is replaced by an ``.npz`` writer
-with the same keys (h5py is used when importable).
+component increase (:309,316), and the missing h5py dependency is replaced by ``h5min`` (the
+subset of HDF5 these files need, in the layout h5py's defaults write; h5py is used when importable).
 """
 import os
 
@@ -17,15 +17,9 @@ from .physics import (ColumnDensity, DopplerParameter, EquivalentWidthFlux, Equi
 from .vpfits import VPfit
 from .vpregion import VPregion
 
-# byte offsets of the contiguous little-endian f8[1000] datasets inside the reference's
-# vamp_1.0/data/simba_*.h5 files (HDF5 v0 layout, parsed once)
-SIMBA_RAW_OFFSETS = {"velocity": 2048, "flux": 10048, "wavelength": 18048, "tau": 28096,
-                     "noise": 36096, "density_col": 44096, "temp": 52096}
-
-
 def read_spectrum_file(path):
-    """wavelength, flux, noise of a spectrum file: HDF5 through h5py when available, the known raw
-    layout of the simba demo files otherwise, or a 4-column text file (wavelength, velocity, flux,
+    """wavelength, flux, noise of a spectrum file: HDF5 (h5py when available, else the minimal
+    reader of vamp_amd/h5min.py), ``.npz``, or a 4-column text file (wavelength, velocity, flux,
     noise) such as vamp_1.0/data/q1422.cont."""
     if path.endswith((".cont", ".txt", ".dat")):
         a = np.loadtxt(path)
@@ -40,11 +34,9 @@ def read_spectrum_file(path):
     if h5py is not None:
         with h5py.File(path, "r") as data:
             return np.array(data["wavelength"][:]), np.array(data["flux"][:]), np.array(data["noise"][:])
-    buf = open(path, "rb").read()
-    if len(buf) != 60096 or buf[:8] != b"\x89HDF\r\n\x1a\n":
-        raise RuntimeError("h5py is not installed and %s does not have the simba demo layout" % path)
-    get = lambda k: np.frombuffer(buf, "<f8", 1000, SIMBA_RAW_OFFSETS[k]).copy()
-    return get("wavelength"), get("flux"), get("noise")
+    from . import h5min
+    data = h5min.read(path)
+    return data["wavelength"], data["flux"], data["noise"]
 
 
 def _same_convolve(a, kernel):
@@ -387,8 +379,9 @@ class VPspectrum():
             plt.close(fig)
 
     def write_file(self):
-        """``params`` and ``flux_model`` (vpspectrum.py:528-538): HDF5 when h5py is importable, else
-        ``.npz`` archives with the same keys."""
+        """``params`` and ``flux_model`` (vpspectrum.py:528-538) as HDF5 files: through h5py when it is
+        importable, else through vamp_amd/h5min.py (same group / dataset structure; a bool such as
+        ``difficult_fit`` is stored as int8)."""
         try:
             import h5py
         except ImportError:
@@ -399,4 +392,5 @@ class VPspectrum():
                     for p in d.keys():
                         f.create_dataset(p, data=np.array(d[p]))
             else:
-                np.savez(self.output_filename + tag + '.npz', **{k: np.array(v) for k, v in d.items()})
+                from . import h5min
+                h5min.write(self.output_filename + tag + '.h5', {k: np.array(v) for k, v in d.items()})
