@@ -92,3 +92,28 @@ def test_voigt_function_static_matches_oracle():
     want = vo.voigt_function(x, 2.4e15 + 9e11, 1.3, 3e10, 8e10)
     assert np.max(np.abs(got - want) / want) < 1e-9      # x re-centring costs a few ulp of (x - c)
     assert VPfit.GaussianWidth(2.0) == 0.8493218002880191
+
+
+@pytest.mark.gpu
+def test_integration_md_stub_runs():
+    """The ctypes stub printed in INTEGRATION.md section 2 (what a reference maintainer would add)
+    is executed as written, against the in-tree library, on a simba H I region."""
+    import os
+    import re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\nimport ctypes as C, numpy as np\n(.*?)```", text, re.S).group(0)
+    code = block[len("```python\n"):-3].replace('"libvamp_hip.so"', repr(os.path.join(ROOT, "vamp_amd", "libvamp_hip.so")))
+    g = load_golden("simba_spectra.npz")
+    s, e = g["H1215_region_pixels"][0]
+    freq, flux, noise = vo.region_from_spectrum(g["H1215_wavelength"], g["H1215_flux"], g["H1215_noise"], int(s), int(e))
+    n, W, seed, iters, thin = 1, 32, 5, 60, 2
+    rng = np.random.default_rng(0)
+    best_theta = np.array([2.0, 0.0, 3.0, 8.0])
+    start_ball = best_theta * (1.0 + 0.01 * rng.standard_normal((W, 4)))
+    env = dict(freq=np.ascontiguousarray(freq), flux=np.ascontiguousarray(flux), noise=np.ascontiguousarray(noise), n=n, W=W,
+               seed=seed, iters=iters, thin=thin, start_ball=start_ball, best_theta=best_theta)
+    exec(compile(code, "INTEGRATION.md", "exec"), env)
+    assert env["chain"].shape == (30, 32, 4) and np.isfinite(env["chain"]).all() and np.isfinite(env["lnp"]).all()
+    assert env["nacc"].sum() > 0 and env["secs"].value > 0
+    assert env["tau"].shape == (1, freq.size) and np.allclose(env["model"], np.exp(-env["tau"][0]))
