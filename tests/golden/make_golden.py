@@ -31,6 +31,7 @@ import types
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE      # where the fixtures are written (tests/test_oracle.py regenerates into a temp dir)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference/vamp_1.0"
@@ -92,7 +93,7 @@ def make_ref_statics():
         c_light=np.array(ref_physics.constants['c']['value']),
         sigma0=np.array(ref_physics.constants['sigma0']['value']),
     )
-    np.savez(os.path.join(HERE, "ref_statics.npz"), **out)
+    np.savez(os.path.join(OUT, "ref_statics.npz"), **out)
     print("ref_statics.npz: reference-computed statics recorded")
 
 
@@ -100,7 +101,7 @@ def make_simba():
     # one of the reference's data files as it is (written by h5py: the real-file fixture of the
     # minimal HDF5 reader / writer, tests/test_h5min.py)
     import shutil
-    shutil.copyfile(os.path.join(REF, "data", "simba_H1215.h5"), os.path.join(HERE, "simba_H1215.h5"))
+    shutil.copyfile(os.path.join(REF, "data", "simba_H1215.h5"), os.path.join(OUT, "simba_H1215.h5"))
     out = {}
     for tag, fn in (("H1215", "simba_H1215.h5"), ("CII1036", "simba_CII1036.h5")):
         d = vo.read_simba_raw(os.path.join(REF, "data", fn))
@@ -118,7 +119,7 @@ def make_simba():
                                           [1231.2313120460688, 1231.8192926966692]])
     out["CII1036_dof_n1"] = np.array([34, 42, 14, 20])   # cell 15
     out["H1215_dof_n1"] = np.array([41, 48, 26])         # cell 25
-    np.savez(os.path.join(HERE, "simba_spectra.npz"), **out)
+    np.savez(os.path.join(OUT, "simba_spectra.npz"), **out)
     print("simba_spectra.npz written")
     return out
 
@@ -156,7 +157,7 @@ def make_wofz_grid():
             for k in range(80, 0, -1):
                 t = mp.mpf(k) / 2 / (z - t)
             wm[n] = float(mp.re(1j / mp.sqrt(mp.pi) / (z - t)))
-    np.savez(os.path.join(HERE, "wofz_grid.npz"), x=x, y=y, re_w=w, mp_idx=idx, mp_re_w=wm)
+    np.savez(os.path.join(OUT, "wofz_grid.npz"), x=x, y=y, re_w=w, mp_idx=idx, mp_re_w=wm)
     rel = np.abs(w[idx] - wm) / wm
     print("wofz_grid.npz: %d points; scipy vs mpmath max rel %.2e" % (x.size, rel.max()))
 
@@ -266,7 +267,7 @@ def make_lnprob_cases(simba):
     out[name + "_flux0"] = vo.model_flux(region, th[0])
     cases.append(name)
     out["cases"] = np.array(cases)
-    np.savez_compressed(os.path.join(HERE, "lnprob_cases.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "lnprob_cases.npz"), **out)
     print("lnprob_cases.npz: %d cases" % len(cases))
 
 
@@ -311,19 +312,8 @@ def make_stretch(simba):
                                      dtype=np.uint64)
     rec["split_b16_s3"] = np.array([vo.split_perm(77, 3, 0, s_, 16) for s_ in range(16)])
     rec["split_b100_s5"] = np.array([vo.split_perm(77, 5, 2, s_, 100) for s_ in range(100)])
-    np.savez_compressed(os.path.join(HERE, "stretch_traj.npz"), **rec)
+    np.savez_compressed(os.path.join(OUT, "stretch_traj.npz"), **rec)
     print("stretch_traj.npz written")
-
-
-if __name__ == "__main__":
-    if not os.path.isdir(REF):
-        sys.exit("run in the build container: /root/reference is required")
-    make_ref_statics()
-    simba = make_simba()
-    make_wofz_grid()
-    make_lnprob_cases(simba)
-    make_stretch(simba)
-    make_q1422()
 
 
 def make_q1422():
@@ -336,6 +326,25 @@ def make_q1422():
     no = np.rint(a[:, 3] * 1e6).astype(np.int32)
     assert np.array_equal(wl / 1000.0, a[:, 0]) and np.array_equal(fl / 1e6, a[:, 2]) and np.array_equal(no / 1e6, a[:, 3])
     px, wv = vo.compute_detection_regions_ref(a[:, 0], a[:, 2], a[:, 3])       # oracle, full-length kernels
-    np.savez_compressed(os.path.join(HERE, "q1422_spectrum.npz"), wavelength_milli=wl, flux_micro=fl, noise_micro=no,
+    np.savez_compressed(os.path.join(OUT, "q1422_spectrum.npz"), wavelength_milli=wl, flux_micro=fl, noise_micro=no,
                         region_pixels=np.array(px, dtype=np.int32))
     print("q1422_spectrum.npz: %d pixels, %d regions" % (wl.size, len(px)))
+
+
+def make_all(out_dir=None):
+    """Write every fixture into ``out_dir`` (default: this directory)."""
+    global OUT
+    if not os.path.isdir(REF):
+        sys.exit("run in the build container: /root/reference is required")
+    if out_dir is not None:
+        OUT = out_dir
+    make_ref_statics()
+    simba = make_simba()
+    make_wofz_grid()
+    make_lnprob_cases(simba)
+    make_stretch(simba)
+    make_q1422()
+
+
+if __name__ == "__main__":
+    make_all(sys.argv[1] if len(sys.argv) > 1 else None)

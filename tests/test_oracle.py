@@ -283,3 +283,26 @@ def test_c_oracle_sampler_matches_python(c_oracle):
     assert rc == 0
     assert np.allclose(X, g["philox_chain_b16"][-1], rtol=1e-10)
     assert np.array_equal(nacc, g["philox_nacc_b16"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/vamp_1.0"), reason="build container only: needs /root/reference")
+def test_committed_fixtures_regenerate_bit_for_bit(tmp_path):
+    """tests/golden/make_golden.py, run as committed, reproduces every committed fixture: same
+    keys, dtypes, shapes and bytes (the .npz containers themselves carry zip timestamps)."""
+    import filecmp
+    import subprocess
+    import sys
+    gold = os.path.join(ROOT, "tests", "golden")
+    subprocess.check_call([sys.executable, os.path.join(gold, "make_golden.py"), str(tmp_path)],
+                          stdout=subprocess.DEVNULL)
+    made = sorted(os.listdir(str(tmp_path)))
+    assert made == sorted(f for f in os.listdir(gold) if f.endswith((".npz", ".h5")))
+    for f in made:
+        a, b = os.path.join(str(tmp_path), f), os.path.join(gold, f)
+        if not f.endswith(".npz"):
+            assert filecmp.cmp(a, b, shallow=False), f
+            continue
+        x, y = np.load(a, allow_pickle=False), np.load(b, allow_pickle=False)
+        assert set(x.files) == set(y.files), f
+        for k in x.files:
+            assert x[k].dtype == y[k].dtype and x[k].shape == y[k].shape and x[k].tobytes() == y[k].tobytes(), (f, k)
