@@ -109,7 +109,8 @@ int vamp_lnprob_all(vamp_ctx* ctx, int64_t W, const double* theta, double* lnpro
 /* Maximum a posteriori search for every region at once: replaces mc.MAP(model).fit(iterlim, tol)
  * (vpfits.py:352-358, 426), i.e. scipy's Nelder-Mead `fmin` on -logp, one region after the other
  * in the reference.  Same simplex rules, start simplex and stopping test as fmin (xtol, ftol,
- * maxiter iterations, maxfun evaluations per region), so each region follows the path fmin would
+ * maxiter iterations, maxfun evaluations per region; maxfun = 0 means scipy's default of 200 per
+ * dimension, which is what PyMC's MAP.fit leaves it at), so each region follows the path fmin would
  * take alone, but an iteration of all regions is one launch.  theta0 / theta_best: the regions'
  * D_r-vectors one after the other; active[n_regions] (may be NULL = all) selects the regions to
  * search, the others are returned unchanged.  A region whose search ends worse than its start

@@ -288,6 +288,38 @@ def test_fp32_humlicek_path():
         ctx.close()
 
 
+@pytest.mark.parametrize("packing", [0, 16])
+def test_config5_q1422_regions_fp32_vs_fp64_oracle(packing):
+    """BASELINE.json config 5 on its own workload: all 421 detected regions of the q1422 spectrum
+    (config 3's batch, 9..478 px, <= 8 Voigt lines each) evaluated in ONE fp32 / Humlicek-W4 launch
+    and compared region by region with the fp64 scipy.wofz oracle.  Stated tolerance
+    (SURVEY 8d): |delta chi^2| / chi^2 <= 1e-3 for every (region, walker)."""
+    import vamp_amd
+    from tools.bench_c3 import build_regions, start_walkers
+    xs, fs, ns, ks = build_regions()
+    assert len(xs) == 421 and sum(len(x) for x in xs) == 27536 and max(ks) <= 8
+    rng = np.random.default_rng(1422)
+    W = 8 if packing == 0 else 16
+    thetas = [start_walkers(rng, x, k, W) for x, k in zip(xs, ks)]
+    ctx = vamp_amd.HipContext(device=0, dtype=vamp_amd.F32)
+    try:
+        ctx.set_packing(packing)
+        ctx.set_regions(xs, fs, ns, ks, mode=vamp_amd.MODE_VOIGT4)
+        got, chi = ctx.lnprob_all(thetas, return_chi2=True)
+    finally:
+        ctx.close()
+    worst = 0.0
+    for r, (x, f, n, k) in enumerate(zip(xs, fs, ns, ks)):
+        reg = vo.Region(x=x, flux=f, noise=n, n_comp=k, mode=vo.MODE_VOIGT4)
+        want, wchi = vo.log_prob_batch(reg, thetas[r], return_chi2=True)
+        assert np.isfinite(want).all() and np.isfinite(got[r]).all(), r
+        rel = np.abs(chi[r] - wchi) / wchi
+        worst = max(worst, rel.max())
+        assert rel.max() <= 1e-3, (r, len(x), k, rel.max())
+        assert np.max(np.abs(got[r] - want) / np.abs(want)) <= 1e-3, r
+    print("config 5: worst relative chi^2 error over 421 regions x %d walkers: %.2e" % (W, worst))
+
+
 def test_full_size_properties(hip_ctx):
     """Headline shape (P = 16384, K = 16; fewer walkers): properties that need no CPU reference.
     (1) batch-position independence, (2) component-permutation invariance, (3) tau is the sum of
@@ -319,6 +351,43 @@ def test_full_size_properties(hip_ctx):
     want = vo.log_prob_batch_fast(r, small["theta0"])
     got = hip_ctx.lnprob(small["theta0"])
     assert np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) <= 1e-9
+
+
+def test_bench_shape_against_oracle(hip_ctx):
+    """The exact shape bench.py times -- P = 16384, K = 16, (N,b,z) D = 48, the workgroup-per-walker
+    kernels with the far-field interpolant and the per-line Taylor tables -- against the oracle
+    directly: lnprob of the bench's own starting walkers (|delta| <= 1e-9 max(1,|lnprob|)) and two
+    full stretch steps with the counter-based draws (identical accept decisions, positions to
+    1e-10).  16 walkers x 262 144 scipy.wofz evaluations each."""
+    from bench import make_workload
+    if hip_ctx.packing_request == 16:
+        pytest.skip("16 components need the one-walker-per-wavefront kernels")
+    wl = make_workload(P=16384, K=16, W=16, nbz=True)
+    assert wl["D"] == 48 and wl["mode"] == vo.MODE_NBZ3
+    hip_ctx.set_regions(wl["x"], wl["flux"], wl["noise"], 16, mode=vo.MODE_NBZ3, nbz=wl["nbz"])
+    l_fixed, line, x_origin, x_scale = [float(v) for v in wl["nbz"][0]]
+    r = vo.Region(x=wl["x"], flux=wl["flux"], noise=wl["noise"], n_comp=16, mode=vo.MODE_NBZ3, l_fixed=l_fixed, line=line,
+                  x_origin=x_origin, x_scale=x_scale)
+    fn = lambda q: vo.log_prob_batch_fast(r, q)
+    want = fn(wl["theta0"])
+    got, chi = hip_ctx.lnprob(wl["theta0"], return_chi2=True)
+    assert np.isfinite(want).all() and np.isfinite(got).all()
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) <= 1e-9
+    assert np.max(np.abs(-0.5 * chi - (want - [vo.log_prior(r, t) for t in wl["theta0"]])) / np.abs(want)) <= 1e-9
+    # tau and flux of one walker, pixel by pixel (k_model: the per-point evaluator)
+    tau, flux = hip_ctx.model(wl["theta0"][0])
+    t0 = vo.component_taus(r, wl["theta0"][0])
+    big = t0 > 1e-290
+    assert np.max(np.abs(tau[big] - t0[big]) / t0[big]) <= 1e-12
+    assert np.allclose(flux, vo.model_flux(r, wl["theta0"][0]), rtol=1e-12, atol=1e-300)
+    # two sampler steps through k_half_step<.., NBZ3, Pack<64,16,false,4,true>> (packing auto / 256)
+    hip_ctx.sampler_init(wl["theta0"], seed=20240517, a=2.0, split_block=16)
+    res = hip_ctx.run(2)
+    chain, lchain, nacc = vo.run_sampler(fn, wl["theta0"], want, 2, seed=20240517, block=16)
+    assert np.array_equal(res["n_accept"], nacc)
+    assert np.allclose(res["chain"], chain, rtol=1e-10, atol=0)
+    assert np.allclose(res["lnprob"], lchain, rtol=1e-9, atol=1e-9)
+    assert nacc.sum() > 0
 
 
 def test_rare_branches_in_long_regions(hip_ctx):
@@ -429,12 +498,16 @@ def test_map_all_follows_scipy_fmin(hip_ctx):
         starts.append(th[np.nanargmax(np.where(np.isfinite(lnp), lnp, -np.inf))].copy())
     hip_ctx.set_regions(xs, fs, ns, Ks, mode=vo.MODE_VOIGT4)
     active = np.array([1, 1, 0, 1], dtype=np.uint8)
-    best, lnp, chi, its = hip_ctx.map_all(starts, iterlim=250, tol=1e-3, active=active)
+    best, lnp, chi, its = hip_ctx.map_all(starts, iterlim=250, tol=1e-3, active=active, xtol=1e-3, maxfun=1000)
+    # PyMC's call (fmin(maxiter=iterlim, ftol=tol), xtol and maxfun at scipy's defaults) is the wrapper's default
+    best_d, lnp_d, _, its_d = hip_ctx.map_all(starts, iterlim=250, tol=1e-3, active=active)
     assert np.array_equal(best[2], starts[2]) and its[2] == 0          # inactive: returned unchanged
     for r in (0, 1, 3):
         def neg(t, r=r):
             v = hip_ctx.lnprob(t, region=r)[0]
             return -v if np.isfinite(v) else 1e300
+        xd, fd, itd, _, _ = fmin(neg, starts[r], ftol=1e-3, maxiter=250, disp=False, full_output=True)
+        assert itd == its_d[r] + 1 and np.allclose(best_d[r], xd, rtol=1e-13, atol=0) and np.isclose(lnp_d[r], -fd, rtol=1e-13)
         xopt, fopt, it, calls, flag = fmin(neg, starts[r], xtol=1e-3, ftol=1e-3, maxiter=250, maxfun=1000, disp=False,
                                            full_output=True)
         assert it == its[r] + 1, (r, it, its[r])          # fmin counts iterations from 1

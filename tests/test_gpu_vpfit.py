@@ -85,6 +85,97 @@ def test_find_bic_reference_flow():
     assert abs(fit.map.BIC - (4 * np.log(nu.size) - 2 * fit.map.lnL)) < 1e-9
 
 
+def _fit_pair(seed, nwalkers):
+    """The product's VPfit twice: on the HIP library, and with the CPU oracle injected as its
+    context (tests/oracle_ctx.py) -- same host logic, same seeds, independent arithmetic."""
+    from oracle_ctx import OracleContext
+    from vamp_amd.vpfits import VPfit
+    g, o = VPfit(seed=seed), VPfit(seed=seed)
+    o._ctx = OracleContext()
+    g.nwalkers = o.nwalkers = nwalkers
+    return g, o
+
+
+@pytest.mark.parametrize("voigt,n", [(False, 1), (True, 2)])
+def test_find_bic_and_chain_covariance_match_oracle(voigt, n):
+    """find_bic (vpfits.py:398-429) against the oracle: three {model, ensemble run, MAP} repeats of 20
+    steps each, short enough that the HIP and the oracle chains coincide walker by walker (same
+    counter-based draws; a rounding-level difference would have to flip an accept decision).  The
+    oracle side samples with vo.run_sampler and finds the MAP with scipy's own fmin, which is what
+    PyMC's MAP.fit runs.  bic_array / red_chi_array agree to 1e-9, the kept chains to 1e-9, and
+    chain_covariance equals np.cov of the oracle's chain (vpfits.py:432-456)."""
+    nu, flux, noise = _hi_region(2)
+    g, o = _fit_pair(seed=3, nwalkers=32)
+    for fit in (g, o):
+        fit.find_bic(nu, flux, n, noise, nu.size - 3 * n, voigt=voigt, iterations=20, thin=1, burn=5)
+    assert len(g.bic_array) == 3 and len(g.red_chi_array) == 3
+    assert np.allclose(g._chain_dev, o._chain_dev, rtol=1e-9, atol=1e-12)
+    assert np.allclose(g.bic_array, o.bic_array, rtol=1e-9, atol=0), (g.bic_array, o.bic_array)
+    assert np.allclose(g.red_chi_array, o.red_chi_array, rtol=1e-9, atol=0), (g.red_chi_array, o.red_chi_array)
+    assert np.isclose(g.map.lnL, o.map.lnL, rtol=1e-9) and np.isclose(g.map.AIC, o.map.AIC, rtol=1e-9)
+    assert np.allclose(g.total.value, o.total.value, rtol=1e-9, atol=1e-300)
+    for k in range(n):
+        for key in g.estimated_variables[k]:
+            assert np.isclose(g.estimated_variables[k][key].value, o.estimated_variables[k][key].value, rtol=1e-9), (k, key)
+    # chain_covariance from the HIP chain == np.cov of the oracle's chain, restated here from
+    # vpfits.py:432-456: rows (amplitude, sigma | GaussianWidth(G_fwhm), centroid), caller units (Hz)
+    cov = g.chain_covariance(n, voigt=voigt)
+    flat = o._chain_dev.reshape(-1, o._ndim)
+    mid, dnu, q = 0.5 * (nu[0] + nu[-1]), (nu[-1] - nu[0]) / (nu.size - 1), 4 if voigt else 3
+    for k in range(n):
+        amp, cen = flat[:, q * k], flat[:, q * k + 1] * dnu + mid
+        sig = flat[:, q * k + 3] * dnu / (2.0 * np.sqrt(2.0 * np.log(2.0))) if voigt else flat[:, q * k + 2] * dnu
+        want = np.cov(np.array((amp, sig, cen)))
+        assert np.allclose(cov[k], want, rtol=1e-7, atol=0), (k, cov[k], want)
+    # the BIC is PyMC 2.3's: k ln(n_data) - 2 lnL with k free scalars (sd included)
+    kfree = (4 if voigt else 3) * n + 1
+    assert abs(g.map.BIC - (kfree * np.log(nu.size) - 2 * g.map.lnL)) < 1e-9
+
+
+def test_region_fit_ladder_matches_oracle(monkeypatch):
+    """VPregion.region_fit (vpregion.py:42-91) on the HIP path and on the oracle: the same sequence
+    of rungs, the same BIC / reduced chi^2 triples on every rung (1e-9) and the same final n."""
+    import vamp_amd.vpregion as vr
+    from oracle_ctx import OracleContext
+    from vamp_amd.vpfits import VPfit
+    nu, flux, noise = _hi_region(0)
+
+    class OracleVPfit(VPfit):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self._ctx = OracleContext()
+
+    def ladder(fit_cls):
+        monkeypatch.setattr(vr, "VPfit", fit_cls)
+        rungs = []
+
+        class Recording(vr.VPregion):
+            def _fit_n(self, n, iterations, thin, burn):
+                fit = super()._fit_n(n, iterations, thin, burn)
+                rungs.append((n, list(fit.bic_array), list(fit.red_chi_array)))
+                return fit
+
+        reg = Recording(nu, flux, noise, voigt=False, chi_limit=1.5, nwalkers=32, seed=21)
+        reg.region_fit(verbose=False, iterations=20, thin=1, burn=5)
+        return reg, rungs
+
+    reg_g, rungs_g = ladder(VPfit)
+    reg_o, rungs_o = ladder(OracleVPfit)
+    assert [r[0] for r in rungs_g] == [r[0] for r in rungs_o] and len(rungs_g) >= 2
+    for (n, bg, cg), (_, bo, co) in zip(rungs_g, rungs_o):
+        assert np.allclose(bg, bo, rtol=1e-9, atol=0), (n, bg, bo)
+        assert np.allclose(cg, co, rtol=1e-9, atol=0), (n, cg, co)
+    assert reg_g.n == reg_o.n and len(reg_g.fit.estimated_profiles) == reg_g.n
+    assert np.allclose(reg_g.fit.total.value, reg_o.fit.total.value, rtol=1e-9, atol=1e-300)
+    # a retry is a new attempt with fresh draws, not a replay (vpspectrum.py:297-348)
+    reg_g.estimate_n()
+    first = rungs_g[0]
+    rungs_g.clear()
+    monkeypatch.setattr(vr, "VPfit", VPfit)
+    reg_g.region_fit(verbose=False, iterations=20, thin=1, burn=5)
+    assert rungs_g[0][0] == first[0] and rungs_g[0][1] != first[1]
+
+
 def test_voigt_function_static_matches_oracle():
     from vamp_amd.vpfits import VPfit
     x = np.linspace(2.4e15, 2.4e15 + 2e12, 257)

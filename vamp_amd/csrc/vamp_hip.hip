@@ -1705,7 +1705,9 @@ int vamp_map_all(vamp_ctx* c, const double* theta0, const uint8_t* active, int64
         for (int r = 0; r < R; ++r) {
             Simplex& s = S[r];
             if (!s.live) continue;
-            if (s.calls >= maxfun || s.it + 1 >= maxiter) { s.live = false; continue; }   // fmin counts from 1
+            // maxfun == 0: scipy's default of 200 evaluations per dimension (what PyMC's MAP.fit leaves it at)
+            const long long fun_cap = maxfun > 0 ? (long long)maxfun : 200ll * s.N;
+            if (s.calls >= fun_cap || s.it + 1 >= maxiter) { s.live = false; continue; }   // fmin counts from 1
             double dx = 0.0, df = 0.0;
             for (int k = 1; k <= s.N; ++k) {
                 df = std::max(df, std::fabs(s.f[0] - s.f[k]));

@@ -144,10 +144,12 @@ class HipContext:
         _lib.check(self._lib.vamp_lnprob_all(self._h, W, _dp(flat), _dp(out), _dp(chi)))
         return (out, chi) if return_chi2 else out
 
-    def map_all(self, starts, iterlim=1000, tol=1e-3, active=None):
+    def map_all(self, starts, iterlim=1000, tol=1e-3, active=None, xtol=1e-4, maxfun=0):
         """Nelder-Mead MAP search of every (active) region at once (vamp_map_all).  starts: one
-        D_r-vector per region.  Returns (best [list of D_r-vectors], lnprob [n_regions],
-        chi2 [n_regions], iterations [n_regions])."""
+        D_r-vector per region.  ``tol`` is fmin's ftol; ``xtol`` and ``maxfun`` default to scipy's
+        1e-4 and 200 evaluations per dimension (maxfun = 0), which is how PyMC 2's
+        ``MAP.fit(iterlim, tol)`` calls fmin (vpfits.py:358).  Returns (best [list of D_r-vectors],
+        lnprob [n_regions], chi2 [n_regions], iterations [n_regions])."""
         vecs = [_f64(np.ravel(t)) for t in starts]
         if len(vecs) != self.n_regions or any(v.size != d for v, d in zip(vecs, self.ndims)):
             raise ValueError("one start vector of the region's dimension per region is required")
@@ -161,7 +163,7 @@ class HipContext:
             if act.size != self.n_regions:
                 raise ValueError("active needs one flag per region")
         _lib.check(self._lib.vamp_map_all(self._h, _dp(flat), None if act is None else act.ctypes.data_as(C.c_void_p),
-                                          int(iterlim), 4 * int(iterlim), float(tol), float(tol), _dp(best), _dp(lnp),
+                                          int(iterlim), int(maxfun), float(xtol), float(tol), _dp(best), _dp(lnp),
                                           _dp(chi), its.ctypes.data_as(_lib.c_int64_p)))
         offs = np.concatenate([[0], np.cumsum(self.ndims)])
         return [best[offs[r]:offs[r + 1]].copy() for r in range(self.n_regions)], lnp, chi, its

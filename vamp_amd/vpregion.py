@@ -29,6 +29,7 @@ class VPregion():
         self.num_pixels = len(flux_array)
         self.nwalkers = nwalkers
         self._seed = seed
+        self._attempt = 0         # region_fit calls so far: a retry must not replay the previous attempt's draws
         self.estimate_n()
         self.set_freedom()
 
@@ -44,7 +45,7 @@ class VPregion():
         self.freedom = self.num_pixels - 3 * self.n
 
     def _fit_n(self, n, iterations, thin, burn):
-        fit = VPfit(seed=None if self._seed is None else self._seed + 1000 * n)
+        fit = VPfit(seed=None if self._seed is None else self._seed + 1000 * n + 1000003 * (self._attempt - 1))
         if self.nwalkers is not None:
             fit.nwalkers = self.nwalkers
         fit.find_bic(self.frequency_array, self.flux_array, n, self.noise_array, self.freedom,
@@ -56,6 +57,7 @@ class VPregion():
         three repeats keeps falling; stop early once the mean reduced chi^2 is under ``chi_limit``.
         The first rung is judged by the LAST of its three BICs, as in the reference (:63)."""
         say = print if verbose else (lambda *a, **k: None)
+        self._attempt += 1
         say("Setting initial number of lines to: {}".format(self.n))
         kept = self._fit_n(self.n, iterations, thin, burn)
         kept_bic = kept.bic_array[-1]
