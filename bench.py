@@ -90,10 +90,74 @@ def algorithmic_bytes_per_walker_step(P, D, s=8):
     return 3 * P * s + 3 * D * s + 2 * s
 
 
-def cpu_baseline(wl, budget_s=12.0):
-    """C oracle (oracle/vamp_oracle.c, OpenMP over walkers) on the host cores: same region, same
-    sampler, a bounded number of walkers for one step.  Test infrastructure used as a reported
-    baseline only."""
+def _pool_lnprob(args):
+    """worker of the named CPU path: numpy + scipy.special.wofz log-posterior of a chunk of walkers"""
+    thetas, = args
+    return _POOL_VO.log_prob_batch_fast(_POOL_REGION, thetas)
+
+
+_POOL_VO = None
+_POOL_REGION = None
+
+
+def _pool_init(region_kw):
+    global _POOL_VO, _POOL_REGION
+    from oracle import vamp_oracle as vo
+    _POOL_VO = vo
+    _POOL_REGION = vo.Region(**region_kw)
+
+
+def cpu_reference_path(wl, budget_s=12.0):
+    """The CPU path the north star names (SURVEY 8d baseline 1, BASELINE.md Baseline A): the
+    log-posterior in numpy + scipy.special.wofz (oracle/vamp_oracle.py: log_prob_batch_fast) and the
+    numpy stretch move (stretch_half_step, same counter-based draws), parallelised over walker
+    chunks with a process pool on the host cores.  One full step of a bounded sub-ensemble of the
+    same workload is timed (pool start-up and the initial log-posteriors are not)."""
+    import multiprocessing as mp
+    from oracle import vamp_oracle as vo
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VAMP_CPU_WORKERS", "128")))
+    kw = dict(x=wl["x"], flux=wl["flux"], noise=wl["noise"], n_comp=wl["K"], mode=wl["mode"])
+    if wl["nbz"] is not None:
+        l_fixed, line, x_origin, x_scale = [float(v) for v in wl["nbz"][0]]
+        kw.update(l_fixed=l_fixed, line=line, x_origin=x_origin, x_scale=x_scale)
+    chunk = 2                                    # walkers per task: 2 x P x K complex temporaries stay in cache
+    with mp.get_context("fork").Pool(cores, initializer=_pool_init, initargs=(kw,)) as pool:
+        def lnprob(q):
+            parts = pool.map(_pool_lnprob, [(q[i:i + chunk],) for i in range(0, q.shape[0], chunk)])
+            return np.concatenate(parts)
+        lnprob(wl["theta0"][:chunk * cores])                               # warms the workers
+        rng = np.random.default_rng(7)
+
+        def one_step(Wc):
+            X = np.ascontiguousarray(wl["theta0"][:Wc].copy())
+            lnp = lnprob(X)                                                  # initial log-posteriors: not timed
+            nacc = 0
+            t0 = time.perf_counter()
+            perm = rng.permutation(Wc)                                       # emcee: shuffled red/blue membership
+            for act, comp in ((perm[:Wc // 2], perm[Wc // 2:]), (perm[Wc // 2:], perm[:Wc // 2])):
+                zz = ((2.0 - 1.0) * rng.random(act.size) + 1.0) ** 2 / 2.0  # a = 2
+                partner = comp[rng.integers(0, comp.size, act.size)]
+                acc, _ = vo.stretch_half_step(X, lnp, act, partner, zz, np.log(rng.random(act.size)), lnprob)
+                nacc += int(acc.sum())
+            return time.perf_counter() - t0, nacc
+
+        Wc = min(wl["W"], 8 * chunk * cores)
+        t, nacc = one_step(Wc)
+        while t < budget_s / 4 and Wc < wl["W"]:                             # grow the sample until it is a few seconds of work
+            Wc = int(min(wl["W"], Wc * min(8.0, max(2.0, 0.7 * budget_s / t))))
+            Wc -= Wc % (2 * chunk)
+            t, nacc = one_step(Wc)
+    return {"value": Wc / t, "unit": "walker-steps/s", "cores": cores, "kind": "port",
+            "path": "numpy + scipy.special.wofz log-posterior + numpy stretch move (oracle/vamp_oracle.py), "
+                    "multiprocessing pool over walker chunks: the CPU path named by BASELINE.json",
+            "sample": f"first {Wc} walkers of the same workload x 1 full step on {cores} processes, {t:.1f} s; "
+                      f"os.cpu_count() = {os.cpu_count()}",
+            "accepted": nacc}
+
+
+def cpu_c_port(wl, budget_s=10.0):
+    """Second, labelled figure: the plain-C restatement (oracle/vamp_oracle.c, OpenMP over walkers,
+    its own straightforward Re w).  Test infrastructure used as a reported baseline only."""
     so = os.path.join(ROOT, "oracle", "libvamp_oracle.so")
     if not os.path.exists(so):
         import subprocess
@@ -126,7 +190,15 @@ def cpu_baseline(wl, budget_s=12.0):
         Wc -= Wc % 1024
     t = run(Wc, 1)
     return {"value": Wc / t, "unit": "walker-steps/s", "cores": cores, "kind": "port",
-            "sample": f"C oracle (OpenMP, {cores} threads), first {Wc} walkers of the same workload x 1 step, {t:.1f} s"}
+            "path": "oracle/vamp_oracle.c (plain C, OpenMP over walkers)",
+            "sample": f"first {Wc} walkers of the same workload x 1 step on {cores} threads, {t:.1f} s"}
+
+
+def cpu_baseline(wl):
+    """`value` is the path BASELINE.json names; the C port is reported beside it."""
+    out = cpu_reference_path(wl)
+    out["c_port"] = cpu_c_port(wl)
+    return out
 
 
 class _StdoutToStderr:
@@ -144,6 +216,16 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
+# fp64 VALU issue roof of one MI355X: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (one DFMA per lane and clock)
+VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9
+FP64_PEAK_TFLOPS = 2.0 * VALU_PEAK_LANE_INSTR / 1e12          # 78.6 (an FMA counts two)
+# builder-counted arithmetic of ONE direct evaluation (DESIGN.md section 3 "flop count"):
+# F_w  = flops of sqrt(pi) Re w(z) incl. forming z and the tau FMA, averaged over this workload's mix of
+#        branches when every (pixel, line) pair is evaluated directly (build e: 45.6 VALU instructions per
+#        pair, 36 of them FMAs) ; F_px = per-pixel epilogue (exp(-tau) 17 FMA + 5, residual, chi^2 FMA)
+F_W_FLOPS, F_PX_FLOPS = 82.0, 46.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,8 +238,10 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="do not record the chain inside the timed region")
+    ap.add_argument("--sustain-seconds", type=float, default=2.5,
+                    help="after the K timed steps, a second run of about this many seconds (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise the nccl process group and run the all-gather even with one rank (rehearsal)")
+                    help="create the RCCL communicator and run the exchange even with one rank (rehearsal)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,6 +252,14 @@ def main():
             sys.exit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    wl = make_workload(P=args.pixels, K=args.components, W=args.walkers, nbz=(args.param == "nbz3"))
+    P, K, W, D = wl["P"], wl["K"], wl["W"], wl["D"]
+
+    # host baseline first: its worker pool forks before this process has touched the GPU
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
+        cpu = cpu_baseline(wl)
+
     import torch
     import vamp_amd
 
@@ -175,80 +267,92 @@ def main():
     quiet.__enter__()
     dist = None
     if world > 1 or args.force_dist:
+        # torch.distributed is the bootstrap channel only (communicator id, barriers, the final max):
+        # gloo on the host.  The per-half-step exchange is RCCL inside libvamp_hip.so.
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
 
-    wl = make_workload(P=args.pixels, K=args.components, W=args.walkers, nbz=(args.param == "nbz3"))
-    P, K, W, D = wl["P"], wl["K"], wl["W"], wl["D"]
     dtype = vamp_amd.F64 if args.dtype == "f64" else vamp_amd.F32
     ctx = vamp_amd.HipContext(device=local_rank, dtype=dtype)
     ctx.set_regions(wl["x"], wl["flux"], wl["noise"], K, mode=wl["mode"], nbz=wl["nbz"])
 
     from vamp_amd.ensemble import ShardedEnsemble
-    torch.cuda.set_device(local_rank)
-    # walker state lives in torch tensors on torch's current stream (plumbing only): the RCCL
-    # all-gather and the chain record are then ordered with the kernels without host syncs
-    ens = ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange="nccl" if dist is not None else "none",
-                          torch_device=torch.device("cuda", local_rank), torch_state=True, exchange_single_rank=args.force_dist)
+    ens = ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange="rccl" if dist is not None else "none",
+                          exchange_single_rank=args.force_dist)
     own = ens.own_count
 
-    # chain storage (device resident): each rank records its own rows every step
-    chain = None
-    if not args.no_chain:
-        chain = torch.empty((args.steps, own, D), dtype=torch.float64, device=torch.device("cuda", local_rank))
-
     def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         ctx.synchronize()
         torch.cuda.synchronize()
 
-    def record(i):
-        if chain is not None:
-            off = 0
-            for rows in ens._own:                            # D2D on the stream the kernels run on
-                chain[i, off:off + rows.shape[0]].copy_(rows, non_blocking=True)
-                off += rows.shape[0]
+    # chain storage (device resident, torch = allocator): every kept step is one device-to-device copy
+    # of the state on the stream the kernels run on, inside the timed region
+    chain = None if args.no_chain else torch.empty((args.steps, W * D), dtype=torch.float64, device=dev)
 
-    ens.step(args.warmup)
+    ens.run_dev(args.warmup)
     sync_all()
     quiet.__exit__()
     ctx.kernel_timing(True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ens.step(1)
-        record(i)
+    ens.run_dev(args.steps, chain_ptr=None if chain is None else chain.data_ptr())
     sync_all()
     dt = time.perf_counter() - t0
     k_ms, k_n = ctx.kernel_timing(False)
 
+    # a longer second run (clocks and caches settled; 20 steps are 0.15 s): same loop, the chain thinned
+    # into the same buffer
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_s = max(args.steps, int(np.ceil(args.sustain_seconds / (dt / args.steps))))
+        thin = int(np.ceil(n_s / args.steps))
+        n_s -= n_s % thin
+        sync_all()
+        ctx.kernel_timing(True)
+        t0 = time.perf_counter()
+        ens.run_dev(n_s, thin=thin, chain_ptr=None if chain is None else chain.data_ptr())
+        sync_all()
+        dts = time.perf_counter() - t0
+        s_ms, s_n = ctx.kernel_timing(False)
+        sustained = {"steps": n_s, "seconds": dts, "chain_thin": thin, "avg_launch_ms": s_ms / max(1, s_n), "launches": s_n}
+
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([dt, sustained["seconds"] if sustained else 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0])
+        if sustained:
+            sustained["seconds"] = float(t[1])
 
     # sanity: the ensemble is alive (some proposals accepted, lnprob finite)
-    _, lnp, nacc, _ = ctx.get_state()
-    acc_frac = float(nacc[ens.own_mask].mean()) / max(1, args.steps + args.warmup)
-    finite_frac = float(np.isfinite(lnp[ens.own_mask]).mean())
+    _, lnp, nacc, n_done = ctx.get_state()
+    acc_frac = float(nacc[ens.own_mask].mean()) / max(1, n_done)
+    finite_frac = float(np.isfinite(lnp).mean())
 
     if rank == 0:
         value = W * args.steps / dt
-        b_alg = algorithmic_bytes_per_walker_step(P, D, 8 if args.dtype == "f64" else 4)
+        s = 8 if args.dtype == "f64" else 4
+        b_alg = algorithmic_bytes_per_walker_step(P, D, s)
         per_launch_units = own // (2 * ens.parts)       # walker-steps of one half-step launch on this rank
         avg_ms = k_ms / max(1, k_n)
-        traffic = None
-        try:      # HBM bytes per launch from the committed PMC run of this same command (tools/pmc.sh)
+        traffic = valu_instr = pmc_src = None
+        try:      # counters of this same command from the committed PMC passes (tools/pmc.sh; separate runs)
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             c = pj["config"]
             if (c["pixels"], c["components"], c["walkers"], c["ndim"], c["n_gpus"], c["dtype"]) == (P, K, W, D, world, args.dtype):
                 traffic = (2.0 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024.0
+                valu_instr = pj.get("SQ_INSTS_VALU_per_launch")
+                pmc_src = pj.get("source")
         except (OSError, KeyError, ValueError):
             pass
         achieved = per_launch_units * b_alg / (avg_ms * 1e-3) / 1e9 if k_n else None
+        flop_ws = P * (K * F_W_FLOPS + F_PX_FLOPS)
         line = {
             "metric": "walker-steps/sec (log-posterior evals/sec)",
             "value": value,
@@ -266,20 +370,44 @@ def main():
                                    f"{'(N,b,z) D=%d' % D if args.param == 'nbz3' else 'native (A,c,L,G) D=%d' % D}, "
                                    f"stretch move a=2, walkers sharded over {world} GPU(s)",
                        "pixels": P, "components": K, "walkers": W, "ndim": D, "parameterisation": args.param,
-                       "chain_recorded": chain is not None},
+                       "chain_recorded": chain is not None,
+                       "exchange": "none" if dist is None else f"in-library RCCL all-gather of the active colour, {ens.parts} piece(s) per half-step"},
+            # contract form: ALGORITHMIC bytes of the launch / its HIP-event duration, against the HBM peak.
+            # The kernel is not HBM-bound (the spectrum is shared by all walkers and stays in L2: see
+            # `traffic`); its binding roof is fp64 VALU issue, reported in `valu` below.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                         "traffic_unit": "bytes of HBM traffic per launch (PMC, separate passes)",
+                         "achieved_is": "algorithmic GB/s (SURVEY 8d bytes per walker-step x walker-steps per launch / launch time)",
+                         "traffic_is": "HBM bytes per launch, (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB, from the committed PMC passes "
+                                       "of this command (not measured in this run: PMC needs separate passes)",
+                         "traffic_source": pmc_src,
                          "measured_hbm_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and k_n) else None,
                          "algorithmic_bytes_per_launch": per_launch_units * b_alg,
                          "kernel": "k_half_step", "avg_launch_ms": avg_ms, "launches": k_n,
-                         "alg_bytes_per_walker_step": b_alg, "walker_steps_per_launch": per_launch_units},
-            "faddeeva_gevals_per_s": value * P * K / 1e9,
+                         "alg_bytes_per_walker_step": b_alg, "walker_steps_per_launch": per_launch_units,
+                         "binding_roof": "fp64 VALU issue",
+                         "valu": None if not (valu_instr and k_n) else {
+                             "peak_lane_instr_per_s": VALU_PEAK_LANE_INSTR,
+                             "executed_lane_instr_per_s": valu_instr * 64 / (avg_ms * 1e-3),
+                             "valu_issue_frac": valu_instr * 64 / (avg_ms * 1e-3) / VALU_PEAK_LANE_INSTR,
+                             "formula": "SQ_INSTS_VALU (wave instructions per launch, committed PMC pass) x 64 lanes / launch time "
+                                        "/ (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz)"},
+                         "flops": {"F_w": F_W_FLOPS, "F_px": F_PX_FLOPS, "flop_per_walker_step": flop_ws,
+                                   "nominal_TFLOPs": value * flop_ws / 1e12 / world, "peak_TFLOPs": FP64_PEAK_TFLOPS,
+                                   "frac_nominal": value * flop_ws / 1e12 / world / FP64_PEAK_TFLOPS,
+                                   "note": "NOMINAL: P (K F_w + F_px) per walker-step as if every (pixel, line) pair were "
+                                           "evaluated directly; the far-field interpolant and the Taylor tables carry out "
+                                           "~30 % of that arithmetic, so the nominal fraction can exceed 1"}},
+            "nominal_faddeeva_gevals_per_s": value * P * K / 1e9,
             "acceptance_fraction": acc_frac,
             "finite_lnprob_fraction": finite_frac,
         }
-        if not args.no_cpu_baseline and args.dtype == "f64" and world == 1:      # rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(wl)
+        if sustained:
+            sustained["value"] = W * sustained["steps"] / sustained["seconds"]
+            sustained["ms_per_step"] = sustained["seconds"] / sustained["steps"] * 1e3
+            line["sustained"] = sustained
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
 
     ctx.close()

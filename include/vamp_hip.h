@@ -33,7 +33,7 @@ enum vamp_status {
     VAMP_OK = 0,
     VAMP_ERR_ARG = -1,      /* bad argument */
     VAMP_ERR_HIP = -2,      /* HIP runtime error */
-    VAMP_ERR_COMM = -3,     /* reserved (collectives are driven by the host through torch.distributed) */
+    VAMP_ERR_COMM = -3,     /* RCCL error (vamp_comm_*, the exchange inside a sharded half-step) */
     VAMP_ERR_NOMEM = -4,    /* out of device or host memory */
     VAMP_ERR_STATE = -5     /* not initialised / wrong call order */
 };
@@ -49,7 +49,8 @@ enum vamp_dtype { VAMP_F64 = 0, VAMP_F32 = 1 };          /* per-pixel arithmetic
 enum vamp_wofz { VAMP_WOFZ_ACCURATE = 0, VAMP_WOFZ_HUMLICEK_W4 = 1 };
 
 #define VAMP_MAX_COMPONENTS 16
-#define VAMP_ABI_VERSION 1
+#define VAMP_ABI_VERSION 2
+#define VAMP_COMM_ID_BYTES 128   /* = NCCL_UNIQUE_ID_BYTES */
 
 /* library identification */
 int vamp_version(void);
@@ -61,8 +62,12 @@ int vamp_device_count(int* n);
  * throughput path of BASELINE.json config 5.  Walker state is always double. */
 int vamp_ctx_create(vamp_ctx** out, int device, int dtype, int wofz_kind);
 int vamp_ctx_destroy(vamp_ctx* ctx);
-/* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the ctx's own */
+/* run on a caller-provided hipStream_t instead of the ctx's own (non-blocking) stream;
+ * hip_stream = NULL returns to the ctx's own stream.  A caller whose other work runs on HIP's
+ * legacy default stream (handle 0: e.g. torch without an explicit stream) adopts THAT stream with
+ * vamp_ctx_set_stream_default -- the ctx's own stream does not synchronise with it. */
 int vamp_ctx_set_stream(vamp_ctx* ctx, void* hip_stream);
+int vamp_ctx_set_stream_default(vamp_ctx* ctx);
 int vamp_ctx_synchronize(vamp_ctx* ctx);
 /* Lanes that serve one walker: 64 (one walker per wavefront), 256 (one walker per 4-wavefront
  * workgroup: each wavefront sweeps every 4th 256-pixel tile and, in fp64, the line cores are read
@@ -146,28 +151,55 @@ int vamp_wofz_re(vamp_ctx* ctx, int64_t n, const double* x, const double* y, dou
  * depend on how walkers are sharded over devices. */
 int vamp_sampler_init(vamp_ctx* ctx, int64_t W, const double* theta0, uint64_t seed, double a,
                       int32_t split_block);
-/* Restrict this ctx to shard `rank` of `world` equal shards of every half-step's active slots
- * (walker-parallel runs of ONE region over several devices).  After each half-step the host
- * all-gathers the walker rows [own_begin, own_end) of the state (RCCL via torch.distributed). */
+/* ---- walker-sharded runs of ONE region over several devices (one process per device) ----
+ * The reference has no multi-device path (do_vamp.py:64-96 is an unfinished process pool over
+ * files); this is the north star's "walkers shard over the GPUs of a node, one all-gather of
+ * walker positions per stretch half-step".  Every device keeps the whole state X[W, D]; in a
+ * half-step a device moves only its share of the active colour, and the rows those walkers end
+ * the half-step with (the ACTIVE colour only: (W/2/world) x (D + 1) doubles per device, position +
+ * lnprob) are all-gathered and scattered into every device's state before the other colour moves.
+ *
+ * vamp_comm_unique_id     rank 0 creates the 128-byte RCCL id and hands it to the other ranks by
+ *                         any host channel (torch.distributed, MPI, a file ...)
+ * vamp_comm_init_rank     collective over the `world` processes: one RCCL communicator per ctx,
+ *                         on the ctx's device; the exchange then runs INSIDE
+ *                         vamp_sampler_half_step / vamp_sampler_run(_dev) on the ctx's streams --
+ *                         no host synchronisation, no torch in the data path.  (SURVEY 8b sketched
+ *                         vamp_comm_init(ctxs, n_dev) for one process driving all devices; the
+ *                         launch contract here is one process per GPU, hence the per-rank form.)
+ * RCCL is loaded with dlopen on first use; single-device runs never touch it. */
+int vamp_comm_unique_id(char id[VAMP_COMM_ID_BYTES]);
+int vamp_comm_init_rank(vamp_ctx* ctx, const char id[VAMP_COMM_ID_BYTES], int rank, int world);
+int vamp_comm_destroy(vamp_ctx* ctx);
+/* Restrict this ctx to shard `rank` of `world` equal shards of every half-step's active slots;
+ * own_begin / own_end receive the rows of the walkers it owns (whole split chunks).  n_accept is
+ * maintained for owned rows only; positions and lnprob are complete on every rank. */
 int vamp_sampler_set_shard(vamp_ctx* ctx, int rank, int world, int64_t* own_begin, int64_t* own_end);
 /* The same with this rank's share cut into `parts` pieces that are stepped and exchanged one
- * after the other, so that the all-gather of piece p overlaps the kernel of piece p + 1.  The
- * ensemble is first cut into `parts` equal row ranges, each of those into `world` shards: piece p
- * of every rank lies in row range p, which makes its all-gather an in-place gather into one
- * contiguous slab.  own_begin / own_end: arrays of `parts` row bounds.  Needs
+ * after the other, so that the exchange of piece p (on the ctx's communication stream) overlaps
+ * the kernel of piece p + 1: safe because a half-step kernel reads only rows of the frozen colour
+ * and writes only its own piece.  The ensemble is first cut into `parts` equal slot ranges, each
+ * of those into `world` shards.  own_begin / own_end: arrays of `parts` row bounds.  Needs
  * W / split_block to be a multiple of world * parts. */
 int vamp_sampler_set_shard_parts(vamp_ctx* ctx, int rank, int world, int parts, int64_t* own_begin,
                                  int64_t* own_end);
+/* Host-staged form of the exchange, for transports other than RCCL (the gloo tests; two ranks
+ * sharing one device): after vamp_sampler_half_step_part(half, part), pack_get copies out this
+ * rank's movers of that piece, rows[part_slots, D + 1]; the caller all-gathers them in rank order
+ * and scatter_put writes rows_all[world * part_slots, D + 1] into the state (same kernels as the
+ * RCCL path on both sides of the wire). */
+int vamp_sampler_pack_get(vamp_ctx* ctx, int part, double* rows);
+int vamp_sampler_scatter_put(vamp_ctx* ctx, int part, const double* rows_all);
 /* Use caller-owned device memory for the walker state (X[total_theta] and lnp[total_walkers],
  * both double), e.g. torch tensors that take part in collectives.  Call before sampler_init. */
 int vamp_sampler_bind_state(vamp_ctx* ctx, void* X_dev, void* lnp_dev);
 int vamp_sampler_state_ptrs(vamp_ctx* ctx, void** X_dev, void** lnp_dev, int64_t* total_theta,
                             int64_t* total_walkers);
 /* one half-step (half = 0 red moves, 1 blue moves), asynchronous on the ctx stream; the step
- * counter advances after half 1 */
+ * counter advances after half 1.  With a communicator it includes the exchange. */
 int vamp_sampler_half_step(vamp_ctx* ctx, int half);
-/* piece `part` of this rank's share only (vamp_sampler_set_shard_parts); the step counter
- * advances after the last piece of half 1.  vamp_sampler_half_step runs all pieces. */
+/* piece `part` of this rank's share only (vamp_sampler_set_shard_parts), WITHOUT exchange; the
+ * step counter advances after the last piece of half 1.  vamp_sampler_half_step runs all pieces. */
 int vamp_sampler_half_step_part(vamp_ctx* ctx, int half, int part);
 /* same with every draw supplied by the host (deterministic-parity hook, single region):
  * active_idx[n], partner_idx[n] walker ids, zz[n] stretch factors, logu[n] = log(u2) */
@@ -178,6 +210,11 @@ int vamp_sampler_half_step_ext(vamp_ctx* ctx, int region, int64_t n, const int32
  * be NULL.  seconds receives the wall time of the sampling loop (device-synchronised). */
 int vamp_sampler_run(vamp_ctx* ctx, int64_t n_steps, int thin, double* chain, double* lnprob_chain,
                      int64_t* n_accept, double* seconds);
+/* the same with the chain kept on the device: chain_dev / lnprob_chain_dev are DEVICE pointers
+ * (caller-owned, same shapes, may be NULL).  Works on sharded contexts with a communicator: every
+ * rank then records the complete state. */
+int vamp_sampler_run_dev(vamp_ctx* ctx, int64_t n_steps, int thin, double* chain_dev,
+                         double* lnprob_chain_dev, double* seconds);
 int vamp_sampler_get_state(vamp_ctx* ctx, double* theta, double* lnprob, int64_t* n_accept,
                            int64_t* step);
 int vamp_sampler_set_state(vamp_ctx* ctx, const double* theta, const double* lnprob, int64_t step);

@@ -43,12 +43,13 @@ def test_ctypes_table_mirrors_header():
 def test_version_and_error_string(libpath):
     from vamp_amd import _lib
     lib = _lib.load()
-    assert lib.vamp_version() == 1
+    assert lib.vamp_version() == 2          # VAMP_ABI_VERSION of include/vamp_hip.h
     assert isinstance(lib.vamp_last_error(), bytes)
     # NULL-argument calls are rejected before any HIP call
     assert lib.vamp_ctx_set_stream(None, None) == -1
     assert b"NULL" in lib.vamp_last_error()
     assert lib.vamp_sampler_half_step(None, 0) == -1
+    assert lib.vamp_comm_init_rank(None, None, 0, 1) == -1 and lib.vamp_sampler_pack_get(None, 0, None) == -1
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -50,16 +50,45 @@ class OracleBackend:
         self.part_slots = [((p * (chunks // parts) + rank * cpp) * hb, (p * (chunks // parts) + (rank + 1) * cpp) * hb)
                            for p in range(parts)]
         self.slot_begin, self.slot_end = self.part_slots[0]
+        self.shard = (rank, world, parts)
+        self.packed = [None] * parts
+        self.moved = [None] * parts
         return [(2 * b, 2 * e) for b, e in self.part_slots]
 
     def half_step_part(self, half, part):
         self.slot_begin, self.slot_end = self.part_slots[part]
         step = self.step
-        self.half_step(half)
+        self._move_slots(half)
+        # what vamp_sampler_pack_get returns: the movers' rows (position + lnprob) in slot order
+        red, blue = vo.split_tables(self.seed, step, self.W, self.block)
+        act = red if half == 0 else blue
+        mine = act[self.slot_begin:self.slot_end]
+        self.packed[part] = np.concatenate([self.X[mine], self.lnp[mine, None]], axis=1)
+        self.moved[part] = act
         if half == 1 and part != len(self.part_slots) - 1:
             self.step = step              # the counter advances after the last piece
 
+    def pack_get(self, part=0):
+        return self.packed[part].copy()
+
+    def scatter_put(self, part, rows_all):
+        """vamp_sampler_scatter_put: rows of piece `part` from all ranks (slot order) -> walker rows"""
+        rank, world, parts = self.shard
+        n = self.part_slots[part][1] - self.part_slots[part][0]
+        first = part * (self.W // 2 // parts)
+        ws = self.moved[part][first:first + world * n]
+        self.X[ws] = rows_all[:, :-1]
+        self.lnp[ws] = rows_all[:, -1]
+
     def half_step(self, half):
+        """all pieces of this rank's share (vamp_sampler_half_step)"""
+        parts = getattr(self, "part_slots", None)
+        if parts is None:
+            return self._move_slots(half)
+        for p in range(len(parts)):
+            self.half_step_part(half, p)
+
+    def _move_slots(self, half):
         red, blue = vo.split_tables(self.seed, self.step, self.W, self.block)
         act, comp = (red, blue) if half == 0 else (blue, red)
         sl = slice(self.slot_begin, self.slot_end)
@@ -158,7 +187,7 @@ def test_piecewise_exchange_is_rank_independent_cpu(world, parts, block, tmp_pat
 def test_single_rank_pieces_match_run_sampler():
     from vamp_amd.ensemble import ShardedEnsemble
     region, X0 = _case()
-    ens = ShardedEnsemble(OracleBackend(region), X0, seed=4242, split_block=8, exchange="none", torch_state=False, parts=4)
+    ens = ShardedEnsemble(OracleBackend(region), X0, seed=4242, split_block=8, exchange="none", parts=4)
     assert ens.own_count == X0.shape[0] and len(ens.own_ranges) == 4
     ens.step(6)
     fn = lambda q: vo.log_prob_batch_fast(region, q)
@@ -170,7 +199,7 @@ def test_single_rank_pieces_match_run_sampler():
 def test_single_rank_driver_matches_run_sampler():
     from vamp_amd.ensemble import ShardedEnsemble
     region, X0 = _case()
-    ens = ShardedEnsemble(OracleBackend(region), X0, seed=4242, split_block=8, exchange="none", torch_state=False)
+    ens = ShardedEnsemble(OracleBackend(region), X0, seed=4242, split_block=8, exchange="none")
     ens.step(6)
     fn = lambda q: vo.log_prob_batch_fast(region, q)
     chain, _, nacc = vo.run_sampler(fn, X0, fn(X0), 6, seed=4242, block=8)
@@ -206,3 +235,108 @@ def test_two_ranks_share_one_gpu_real_kernels(tmp_path):
     fn = lambda q: vo.log_prob_batch_fast(region, q)
     chain, _, nacc = vo.run_sampler(fn, X0, fn(X0), 6, seed=4242, block=8)
     assert np.allclose(r["X"], chain[-1], rtol=1e-10, atol=1e-12) and np.array_equal(r["nacc"], nacc)
+
+
+def _big_case(W=512):
+    region, _ = _case()
+    rng = np.random.default_rng(18)
+    X0 = np.stack([rng.uniform(0.3, 1.5, W), rng.uniform(-4, 4, W), rng.uniform(0.5, 3, W), rng.uniform(2, 8, W)], 1)
+    return region, X0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parts", [1, 2, 4])
+def test_in_library_rccl_exchange_single_rank(parts):
+    """The production exchange path on one GPU: an RCCL communicator of one rank inside the library
+    (vamp_comm_init_rank), movers packed by the half-step kernel, ncclAllGather + scatter on the
+    library's streams (communication stream when the share is cut into pieces), the whole loop in
+    one vamp_sampler_run_dev call.  Same trajectory as the plain sampler, bit for bit, and the packed
+    rows are exactly the rows the movers ended with."""
+    import vamp_amd
+    from vamp_amd.ensemble import ShardedEnsemble
+    region, X0 = _big_case()
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+        ctx.sampler_init(X0, seed=99, split_block=32)
+        ref = ctx.run(8)
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+        ens = ShardedEnsemble(ctx, X0, seed=99, split_block=32, exchange="rccl", exchange_single_rank=True, parts=parts)
+        assert ens.parts == parts and ens.own_count == X0.shape[0]
+        ens.step(3)                               # half-step by half-step from the host
+        X3, lnp3, _, step = ctx.get_state()
+        assert step == 3 and np.array_equal(X3, ref["chain"][2]) and np.array_equal(lnp3, ref["lnprob"][2])
+        # the movers of the last (blue) half-step, as packed for the wire
+        red, blue = vo.split_tables(99, 2, X0.shape[0], 32)
+        n = X0.shape[0] // 2 // parts
+        for p in range(parts):
+            rows = ctx.pack_get(p)
+            ws = blue[p * n:(p + 1) * n]
+            assert np.array_equal(rows[:, :-1], X3[ws]) and np.array_equal(rows[:, -1], lnp3[ws])
+        res = ctx.run(5)                          # the same through vamp_sampler_run
+        assert np.array_equal(res["chain"], ref["chain"][3:]) and np.array_equal(res["n_accept"], ref["n_accept"])
+
+
+@pytest.mark.gpu
+def test_scatter_rewrites_foreign_rows_only():
+    """vamp_sampler_scatter_put on a 2-shard context: rows of the other rank's movers are written
+    where this (step, half) puts those slots, own rows and the frozen colour are left alone."""
+    import vamp_amd
+    region, X0 = _big_case(64)
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+        ctx.sampler_init(X0, seed=5, split_block=16)
+        (b, e), = ctx.sampler_set_shard_parts(1, 2, 1)            # this ctx plays rank 1 of 2
+        assert (b, e) == (32, 64)
+        ctx.half_step_part(0, 0)
+        mine = ctx.pack_get(0)
+        X1, lnp1, _, _ = ctx.get_state()
+        red, blue = vo.split_tables(5, 0, 64, 16)
+        assert np.array_equal(mine[:, :-1], X1[red[16:]]) and np.array_equal(mine[:, -1], lnp1[red[16:]])
+        foreign = np.arange(16 * 5, dtype=np.float64).reshape(16, 5) + 1000.0
+        ctx.scatter_put(0, np.concatenate([foreign, -mine]))          # own block deliberately wrong: must be ignored
+        X2, lnp2, _, _ = ctx.get_state()
+        assert np.array_equal(X2[red[:16]], foreign[:, :-1]) and np.array_equal(lnp2[red[:16]], foreign[:, -1])
+        keep = np.ones(64, dtype=bool)
+        keep[red[:16]] = False
+        assert np.array_equal(X2[keep], X1[keep]) and np.array_equal(lnp2[keep], lnp1[keep])
+
+
+@pytest.mark.gpu
+def test_default_stream_orders_with_torch_and_run_dev_records_on_device():
+    """(1) vamp_ctx_set_stream_default: half-steps issued on HIP's legacy default stream are ordered
+    with torch work on torch's default stream -- snapshots of the bound state taken from the torch
+    side after every step, with no host synchronisation in between, equal the chain of a plain run.
+    (2) vamp_sampler_run_dev writes the chain into caller-owned device memory."""
+    import torch
+    import vamp_amd
+    region, X0 = _big_case(2048)
+    dev = torch.device("cuda", 0)
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+        ctx.sampler_init(X0, seed=31, split_block=64)
+        ref = ctx.run(6)
+        # (2) device-resident chain
+        ctx.sampler_init(X0, seed=31, split_block=64)
+        chain_t = torch.zeros((3, X0.size), dtype=torch.float64, device=dev)
+        lnp_t = torch.zeros((3, X0.shape[0]), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        ctx.run_dev(6, thin=2, chain_ptr=chain_t.data_ptr(), lnprob_ptr=lnp_t.data_ptr())
+        assert np.array_equal(chain_t.cpu().numpy().reshape(3, *X0.shape), ref["chain"][1::2])
+        assert np.array_equal(lnp_t.cpu().numpy(), ref["lnprob"][1::2])
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+        X_t = torch.empty(X0.size, dtype=torch.float64, device=dev)
+        L_t = torch.empty(X0.shape[0], dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        ctx.set_stream_default()
+        ctx.sampler_bind_state(X_t.data_ptr(), L_t.data_ptr())
+        ctx.sampler_init(X0, seed=31, split_block=64)
+        snaps = []
+        for _ in range(6):
+            ctx.half_step(0)
+            ctx.half_step(1)
+            snaps.append(X_t.clone())             # torch's default stream: ordered after the kernels
+        torch.cuda.synchronize()
+        got = np.stack([s.cpu().numpy().reshape(X0.shape) for s in snaps])
+        assert np.array_equal(got, ref["chain"])

@@ -26,6 +26,7 @@ SIGNATURES = {
     "vamp_ctx_create": (C.c_int, [c_void_pp, C.c_int, C.c_int, C.c_int]),
     "vamp_ctx_destroy": (C.c_int, [C.c_void_p]),
     "vamp_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vamp_ctx_set_stream_default": (C.c_int, [C.c_void_p]),
     "vamp_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "vamp_ctx_set_packing": (C.c_int, [C.c_void_p, C.c_int]),
     "vamp_set_regions": (C.c_int, [C.c_void_p, C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_int32_p,
@@ -41,6 +42,12 @@ SIGNATURES = {
     "vamp_sampler_init": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_uint64, C.c_double, C.c_int32]),
     "vamp_sampler_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int64_p, c_int64_p]),
     "vamp_sampler_set_shard_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int64_p, c_int64_p]),
+    "vamp_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "vamp_comm_init_rank": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "vamp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "vamp_sampler_pack_get": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    "vamp_sampler_scatter_put": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    "vamp_sampler_run_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, c_double_p]),
     "vamp_sampler_bind_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "vamp_sampler_state_ptrs": (C.c_int, [C.c_void_p, c_void_pp, c_void_pp, c_int64_p, c_int64_p]),
     "vamp_sampler_half_step": (C.c_int, [C.c_void_p, C.c_int]),

@@ -24,6 +24,7 @@
 //           accept test / state update follow `reduce` in the same launch.
 // No MFMA (nothing here is a contraction), no atomics, no inter-workgroup communication.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1061,6 +1062,8 @@ struct SamplerDev {
     double* lnp;                 // [n_regions * W]
     long long* n_accept;         // [n_regions * W]
     long long slot_begin, slot_end;   // this ctx's share of the n_regions*W/2 active slots
+    double* pack;                // walker-sharded runs: [slot - slot_begin][D + 1] = the mover's row and lnprob
+                                 // after the accept step (what the other devices need), else nullptr
 };
 
 // One half-step of the stretch move, one wavefront per active walker.
@@ -1140,6 +1143,12 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
     const double lnp_s = S.lnp[wg];
     const double diff = (double)(R.D - 1) * log(z) + lnp_q - lnp_s;
     const bool accept = logu < diff;                      // false for NaN
+    if (!EXT && S.pack) {
+        // active-colour exchange: the row this walker ends the half-step with, in slot order
+        double* pk = S.pack + (slot - S.slot_begin) * (long long)(R.D + 1);
+        for (int d = l; d < R.D; d += PK::LPW) pk[d] = accept ? L.theta[d] : Xs[d];
+        if (l == 0) pk[R.D] = accept ? lnp_q : lnp_s;
+    }
     if (accept) {
         for (int d = l; d < R.D; d += PK::LPW) Xs[d] = L.theta[d];
         if (l == 0) {
@@ -1147,6 +1156,28 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
             S.n_accept[wg] += 1;
         }
     }
+}
+
+// Walker-sharded runs: rows of the active colour gathered from every device, in slot order
+// (recv[i] = slot first_slot + i, D + 1 doubles: position and lnprob), are written to the walkers
+// that hold those slots in this (step, half).  16 lanes per row; rows [own_lo, own_hi) are this
+// device's own movers, already in place.
+__global__ __launch_bounds__(256) void k_scatter_rows(SamplerDev S, const double* __restrict__ recv, unsigned step, int half,
+                                                      long long first_slot, long long n_rows, long long own_lo, long long own_hi) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    if (i >= n_rows || (i >= own_lo && i < own_hi)) return;
+    const RegionDev& R = S.regions[0];
+    const int D = R.D;
+    const long long slot = first_slot + i;
+    const unsigned hb = (unsigned)(S.split_block >> 1);
+    const unsigned chunk = (unsigned)(slot / hb), pos = (unsigned)(slot % hb);
+    const long long ws = (long long)chunk * S.split_block +
+                         split_perm(S.seed, step, chunk, 0u, pos + (half ? hb : 0u), (unsigned)S.split_block);
+    const double* src = recv + i * (long long)(D + 1);
+    double* dst = S.X + R.theta_off + ws * D;
+    for (int d = l; d < D; d += 16) dst[d] = src[d];
+    if (l == 0) S.lnp[R.walker_off + ws] = src[D];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1226,6 +1257,15 @@ struct vamp_ctx {
     long long slot_begin = 0, slot_end = 0;      // part 0 (the whole share when shard_parts == 1)
     int shard_rank = 0, shard_world = 1, shard_parts = 1;
     long long part_slots = 0, part_stride = 0;   // slots per part; distance between this rank's parts
+    // walker-sharded runs: active-colour exchange (pack -> all-gather -> scatter), see vamp_comm_*
+    double* send_d = nullptr;        // [parts][part_slots][D + 1]
+    double* recv_d = nullptr;        // [parts][world * part_slots][D + 1]
+    std::vector<unsigned> part_step; // (step, half) of the last launch of every part
+    std::vector<int> part_half;
+    void* comm = nullptr;            // ncclComm_t (RCCL), one per ctx
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t comm_stream = nullptr;
+    std::vector<hipEvent_t> ev_kernel, ev_scatter;   // per part: kernel done / rows scattered
     // grow-only scratch of vamp_lnprob (the MAP optimiser calls it thousands of times with W = 1)
     double *sc_th = nullptr, *sc_lp = nullptr, *sc_chi = nullptr;
     size_t sc_th_cap = 0, sc_w_cap = 0;
@@ -1261,6 +1301,9 @@ int free_sampler(vamp_ctx* c) {
     if (c->X_d && !c->X_ext) (void)hipFree(c->X_d);
     if (c->lnp_d && !c->X_ext) (void)hipFree(c->lnp_d);
     if (c->nacc_d) (void)hipFree(c->nacc_d);
+    if (c->send_d) (void)hipFree(c->send_d);
+    if (c->recv_d) (void)hipFree(c->recv_d);
+    c->send_d = c->recv_d = nullptr;
     c->X_d = nullptr;
     c->lnp_d = nullptr;
     c->nacc_d = nullptr;
@@ -1301,6 +1344,11 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     S.n_accept = c->nacc_d;
     S.slot_begin = c->slot_begin + part * c->part_stride;
     S.slot_end = c->shard_parts > 1 ? S.slot_begin + c->part_slots : c->slot_end;
+    S.pack = (!ext && c->send_d) ? c->send_d + (long long)part * c->part_slots * (c->regions_h[0].D + 1) : nullptr;
+    if (!ext && c->send_d) {
+        c->part_step[part] = (unsigned)c->step;
+        c->part_half[part] = half;
+    }
     const long long n = ext ? ext_n : (S.slot_end - S.slot_begin);
     if (n <= 0) return 0;
     // <16 lanes, 8 lines> packing needs every wave inside one region and one shard
@@ -1355,6 +1403,128 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     return 0;
 }
 
+// ---- RCCL, bound at run time ------------------------------------------------------------------
+// Only walker-sharded multi-GPU runs need it, so the library does not link librccl: the few entry
+// points are resolved with dlopen on first use (the copy already mapped into the process, e.g. by
+// torch, wins; else /opt/rocm/lib).  Prototypes as in rccl/rccl.h (NCCL API).
+struct RcclUniqueId { char internal[VAMP_COMM_ID_BYTES]; };
+struct RcclApi {
+    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+constexpr int RCCL_FLOAT64 = 8;       // ncclFloat64 / ncclDouble
+
+int rccl_api(RcclApi** out) {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (h) {
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+            api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+            api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+        }
+    }
+    if (!api.ok) return fail(VAMP_ERR_COMM, "RCCL is not available (librccl.so could not be loaded)");
+    *out = &api;
+    return VAMP_OK;
+}
+#define RCCL_TRY(api, expr)                                                                   \
+    do {                                                                                      \
+        int r_ = (expr);                                                                      \
+        if (r_ != 0) return fail(VAMP_ERR_COMM, std::string(#expr) + ": " + (api)->GetErrorString(r_)); \
+    } while (0)
+
+// rows of part `part` gathered in c->recv_d -> walker rows (on `st`)
+int launch_scatter(vamp_ctx* c, int part, hipStream_t st) {
+    SamplerDev S;
+    std::memset(&S, 0, sizeof(S));
+    S.regions = c->regions_d;
+    S.n_regions = c->n_regions;
+    S.W = c->W;
+    S.split_block = c->split_block;
+    S.a = c->a;
+    S.seed = c->seed;
+    S.X = c->X_d;
+    S.lnp = c->lnp_d;
+    S.n_accept = c->nacc_d;
+    const long long n_rows = (long long)c->shard_world * c->part_slots;
+    const long long own_lo = (long long)c->shard_rank * c->part_slots;
+    const double* recv = c->recv_d + (long long)part * n_rows * (c->regions_h[0].D + 1);
+    const unsigned grid = (unsigned)((n_rows * 16 + 255) / 256);
+    hipLaunchKernelGGL(k_scatter_rows, dim3(grid), dim3(256), 0, st, S, recv, c->part_step[part], c->part_half[part],
+                       (long long)part * c->part_stride, n_rows, own_lo, own_lo + c->part_slots);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// after launch_half(part): all-gather the part's movers over RCCL and scatter them.  With several
+// parts the exchange runs on the communication stream, so that it overlaps the next part's kernel.
+int exchange_part(vamp_ctx* c, int part) {
+    RcclApi* api = nullptr;
+    int rc = rccl_api(&api);
+    if (rc) return rc;
+    const long long row = c->regions_h[0].D + 1;
+    const size_t count = (size_t)(c->part_slots * row);
+    const double* send = c->send_d + (long long)part * c->part_slots * row;
+    double* recv = c->recv_d + (long long)part * c->shard_world * c->part_slots * row;
+    const bool overlap = c->shard_parts > 1;
+    hipStream_t st = overlap ? c->comm_stream : c->stream;
+    if (overlap) {
+        HIP_TRY(hipEventRecord(c->ev_kernel[part], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_kernel[part], 0));
+    }
+    RCCL_TRY(api, api->AllGather(send, recv, count, RCCL_FLOAT64, c->comm, st));
+    rc = launch_scatter(c, part, st);
+    if (rc) return rc;
+    if (overlap) HIP_TRY(hipEventRecord(c->ev_scatter[part], c->comm_stream));
+    return 0;
+}
+
+// one half-step of this device's whole share; with a communicator, followed by the exchange
+int half_step_all(vamp_ctx* c, int half) {
+    for (int p = 0; p < c->shard_parts; ++p) {
+        int rc = launch_half(c, half, false, 0, 0, p);
+        if (rc) return rc;
+        if (c->comm && c->send_d) {
+            rc = exchange_part(c, p);
+            if (rc) return rc;
+        }
+    }
+    if (c->comm && c->send_d && c->shard_parts > 1)
+        for (int p = 0; p < c->shard_parts; ++p) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_scatter[p], 0));
+    return 0;
+}
+
+int free_comm(vamp_ctx* c) {
+    if (c->comm) {
+        RcclApi* api = nullptr;
+        if (rccl_api(&api) == 0) (void)api->CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    for (hipEvent_t e : c->ev_kernel) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_scatter) (void)hipEventDestroy(e);
+    c->ev_kernel.clear();
+    c->ev_scatter.clear();
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    c->comm_stream = nullptr;
+    c->comm_rank = 0;
+    c->comm_world = 1;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1397,6 +1567,8 @@ int vamp_ctx_destroy(vamp_ctx* c) {
     if (!c) return VAMP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    free_comm(c);
     free_sampler(c);
     free_regions(c);
     for (void* p : {(void*)c->ext_act_d, (void*)c->ext_par_d, (void*)c->ext_z_d, (void*)c->ext_lu_d, (void*)c->sc_th,
@@ -1415,6 +1587,13 @@ int vamp_ctx_set_stream(vamp_ctx* c, void* hip_stream) {
     if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_set_stream: ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return VAMP_OK;
+}
+
+int vamp_ctx_set_stream_default(vamp_ctx* c) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_set_stream_default: ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = nullptr;       // HIP's legacy default stream: what callers that never create a stream run on
     return VAMP_OK;
 }
 
@@ -1929,6 +2108,8 @@ int vamp_sampler_set_shard_parts(vamp_ctx* c, int rank, int world, int parts, in
     if (world < 1 || rank < 0 || rank >= world) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: bad rank/world");
     if (parts < 1 || parts > 64) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: parts must be in 1..64");
     if (c->n_regions != 1) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: walker sharding is for single-region contexts (shard regions across devices otherwise)");
+    if (c->comm && (world != c->comm_world || rank != c->comm_rank))
+        return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: rank/world differ from the communicator's (vamp_comm_init_rank)");
     const long long chunks = c->W / c->split_block;
     if (chunks % ((long long)world * parts)) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: W/split_block must be a multiple of world * parts");
     // the ensemble is cut into `parts` equal row ranges and each of those into `world` shards:
@@ -1942,6 +2123,28 @@ int vamp_sampler_set_shard_parts(vamp_ctx* c, int rank, int world, int parts, in
     c->part_stride = (chunks / parts) * hb;
     c->slot_begin = rank * cpp * hb;
     c->slot_end = c->slot_begin + c->part_slots;      // of part 0
+    // exchange buffers: the movers of every part in slot order, position + lnprob per row
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->send_d) (void)hipFree(c->send_d);
+    if (c->recv_d) (void)hipFree(c->recv_d);
+    c->send_d = c->recv_d = nullptr;
+    if (world > 1 || c->comm) {
+        const size_t row = (size_t)c->regions_h[0].D + 1;
+        HIP_TRY(hipMalloc(&c->send_d, (size_t)parts * c->part_slots * row * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->recv_d, (size_t)parts * world * c->part_slots * row * sizeof(double)));
+        c->part_step.assign(parts, 0u);
+        c->part_half.assign(parts, 0);
+        if (c->comm) {
+            while ((int)c->ev_kernel.size() < parts) {
+                hipEvent_t a, b;
+                HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+                c->ev_kernel.push_back(a);
+                c->ev_scatter.push_back(b);
+            }
+        }
+    }
     for (int p = 0; p < parts; ++p) {
         const long long first = p * (chunks / parts) + rank * cpp;
         if (own_begin) own_begin[p] = first * c->split_block;
@@ -1969,10 +2172,8 @@ int vamp_sampler_half_step(vamp_ctx* c, int half) {
     if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_half_step: call vamp_sampler_init first");
     if (half != 0 && half != 1) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step: half must be 0 or 1");
     HIP_TRY(hipSetDevice(c->device));
-    for (int p = 0; p < c->shard_parts; ++p) {
-        int rc = launch_half(c, half, false, 0, 0, p);
-        if (rc) return rc;
-    }
+    int rc = half_step_all(c, half);
+    if (rc) return rc;
     if (half == 1) c->step += 1;
     return VAMP_OK;
 }
@@ -1982,6 +2183,8 @@ int vamp_sampler_half_step_part(vamp_ctx* c, int half, int part) {
     if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_half_step_part: call vamp_sampler_init first");
     if (half != 0 && half != 1) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_part: half must be 0 or 1");
     if (part < 0 || part >= c->shard_parts) return fail(VAMP_ERR_ARG, "vamp_sampler_half_step_part: no such part");
+    if (c->comm && c->send_d)
+        return fail(VAMP_ERR_STATE, "vamp_sampler_half_step_part: with a communicator the exchange is part of vamp_sampler_half_step / vamp_sampler_run");
     HIP_TRY(hipSetDevice(c->device));
     int rc = launch_half(c, half, false, 0, 0, part);
     if (rc) return rc;
@@ -2027,33 +2230,30 @@ int vamp_sampler_half_step_ext(vamp_ctx* c, int region, int64_t n, const int32_t
     return VAMP_OK;
 }
 
-int vamp_sampler_run(vamp_ctx* c, int64_t n_steps, int thin, double* chain, double* lnprob_chain, int64_t* n_accept,
-                     double* seconds) {
-    if (!c) return fail(VAMP_ERR_ARG, "vamp_sampler_run: ctx is NULL");
-    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_run: call vamp_sampler_init first");
-    if (n_steps < 0 || thin < 1) return fail(VAMP_ERR_ARG, "vamp_sampler_run: n_steps >= 0 and thin >= 1 required");
-    if (c->shard_world != 1) return fail(VAMP_ERR_STATE, "vamp_sampler_run: sharded contexts are stepped by the host (half_step + all-gather)");
+int vamp_sampler_run_dev(vamp_ctx* c, int64_t n_steps, int thin, double* chain_dev, double* lnprob_chain_dev, double* seconds) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_sampler_run_dev: ctx is NULL");
+    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_run_dev: call vamp_sampler_init first");
+    if (n_steps < 0 || thin < 1) return fail(VAMP_ERR_ARG, "vamp_sampler_run_dev: n_steps >= 0 and thin >= 1 required");
+    if (c->shard_world != 1 && !(c->comm && c->send_d))
+        return fail(VAMP_ERR_STATE, "vamp_sampler_run_dev: a sharded context without a communicator is stepped by the host "
+                                    "(half_step_part + pack_get / scatter_put)");
     HIP_TRY(hipSetDevice(c->device));
     const long long n_keep = n_steps / thin;
-    DevBuf chain_b, lchain_b;
-    if (chain && n_keep) HIP_TRY(hipMalloc(&chain_b.p, (size_t)n_keep * c->total_theta * sizeof(double)));
-    if (lnprob_chain && n_keep) HIP_TRY(hipMalloc(&lchain_b.p, (size_t)n_keep * c->total_walkers * sizeof(double)));
-    double *chain_d = chain_b.as<double>(), *lchain_d = lchain_b.as<double>();
     HIP_TRY(hipStreamSynchronize(c->stream));
     const auto t0 = std::chrono::steady_clock::now();
     long long kept = 0;
     for (long long it = 0; it < n_steps; ++it) {
         for (int half = 0; half < 2; ++half) {
-            int rc = launch_half(c, half, false, 0, 0);
+            int rc = half_step_all(c, half);
             if (rc) return rc;
         }
         c->step += 1;
         if ((it + 1) % thin == 0 && kept < n_keep) {
-            if (chain_d)
-                HIP_TRY(hipMemcpyAsync(chain_d + kept * c->total_theta, c->X_d, c->total_theta * sizeof(double),
+            if (chain_dev)
+                HIP_TRY(hipMemcpyAsync(chain_dev + kept * c->total_theta, c->X_d, c->total_theta * sizeof(double),
                                        hipMemcpyDeviceToDevice, c->stream));
-            if (lchain_d)
-                HIP_TRY(hipMemcpyAsync(lchain_d + kept * c->total_walkers, c->lnp_d, c->total_walkers * sizeof(double),
+            if (lnprob_chain_dev)
+                HIP_TRY(hipMemcpyAsync(lnprob_chain_dev + kept * c->total_walkers, c->lnp_d, c->total_walkers * sizeof(double),
                                        hipMemcpyDeviceToDevice, c->stream));
             ++kept;
         }
@@ -2061,6 +2261,22 @@ int vamp_sampler_run(vamp_ctx* c, int64_t n_steps, int thin, double* chain, doub
     HIP_TRY(hipStreamSynchronize(c->stream));
     const auto t1 = std::chrono::steady_clock::now();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    return VAMP_OK;
+}
+
+int vamp_sampler_run(vamp_ctx* c, int64_t n_steps, int thin, double* chain, double* lnprob_chain, int64_t* n_accept,
+                     double* seconds) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_sampler_run: ctx is NULL");
+    if (!c->sampler_ready) return fail(VAMP_ERR_STATE, "vamp_sampler_run: call vamp_sampler_init first");
+    if (n_steps < 0 || thin < 1) return fail(VAMP_ERR_ARG, "vamp_sampler_run: n_steps >= 0 and thin >= 1 required");
+    HIP_TRY(hipSetDevice(c->device));
+    const long long n_keep = n_steps / thin;
+    DevBuf chain_b, lchain_b;
+    if (chain && n_keep) HIP_TRY(hipMalloc(&chain_b.p, (size_t)n_keep * c->total_theta * sizeof(double)));
+    if (lnprob_chain && n_keep) HIP_TRY(hipMalloc(&lchain_b.p, (size_t)n_keep * c->total_walkers * sizeof(double)));
+    double *chain_d = chain_b.as<double>(), *lchain_d = lchain_b.as<double>();
+    int rc = vamp_sampler_run_dev(c, n_steps, thin, chain_d, lchain_d, seconds);
+    if (rc) return rc;
     if (chain_d) {
         HIP_TRY(hipMemcpy(chain, chain_d, (size_t)n_keep * c->total_theta * sizeof(double), hipMemcpyDeviceToHost));
     }
@@ -2068,6 +2284,70 @@ int vamp_sampler_run(vamp_ctx* c, int64_t n_steps, int thin, double* chain, doub
         HIP_TRY(hipMemcpy(lnprob_chain, lchain_d, (size_t)n_keep * c->total_walkers * sizeof(double), hipMemcpyDeviceToHost));
     }
     if (n_accept) HIP_TRY(hipMemcpy(n_accept, c->nacc_d, c->total_walkers * sizeof(long long), hipMemcpyDeviceToHost));
+    return VAMP_OK;
+}
+
+// ---- walker-sharded multi-GPU runs ------------------------------------------------------------
+int vamp_comm_unique_id(char* id) {
+    if (!id) return fail(VAMP_ERR_ARG, "vamp_comm_unique_id: id is NULL");
+    RcclApi* api = nullptr;
+    int rc = rccl_api(&api);
+    if (rc) return rc;
+    RcclUniqueId u;
+    RCCL_TRY(api, api->GetUniqueId(&u));
+    std::memcpy(id, u.internal, VAMP_COMM_ID_BYTES);
+    return VAMP_OK;
+}
+
+int vamp_comm_init_rank(vamp_ctx* c, const char* id, int rank, int world) {
+    if (!c || !id) return fail(VAMP_ERR_ARG, "vamp_comm_init_rank: NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(VAMP_ERR_ARG, "vamp_comm_init_rank: bad rank/world");
+    if (c->comm) return fail(VAMP_ERR_STATE, "vamp_comm_init_rank: the context already has a communicator");
+    RcclApi* api = nullptr;
+    int rc = rccl_api(&api);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    RcclUniqueId u;
+    std::memcpy(u.internal, id, VAMP_COMM_ID_BYTES);
+    void* comm = nullptr;
+    RCCL_TRY(api, api->CommInitRank(&comm, world, u, rank));
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    return VAMP_OK;
+}
+
+int vamp_comm_destroy(vamp_ctx* c) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_comm_destroy: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    free_comm(c);
+    return VAMP_OK;
+}
+
+int vamp_sampler_pack_get(vamp_ctx* c, int part, double* rows) {
+    if (!c || !rows) return fail(VAMP_ERR_ARG, "vamp_sampler_pack_get: NULL argument");
+    if (!c->sampler_ready || !c->send_d) return fail(VAMP_ERR_STATE, "vamp_sampler_pack_get: no sharded sampler (vamp_sampler_set_shard_parts with world > 1)");
+    if (part < 0 || part >= c->shard_parts) return fail(VAMP_ERR_ARG, "vamp_sampler_pack_get: no such part");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->part_slots * (c->regions_h[0].D + 1);
+    HIP_TRY(hipMemcpy(rows, c->send_d + (size_t)part * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    return VAMP_OK;
+}
+
+int vamp_sampler_scatter_put(vamp_ctx* c, int part, const double* rows_all) {
+    if (!c || !rows_all) return fail(VAMP_ERR_ARG, "vamp_sampler_scatter_put: NULL argument");
+    if (!c->sampler_ready || !c->recv_d) return fail(VAMP_ERR_STATE, "vamp_sampler_scatter_put: no sharded sampler (vamp_sampler_set_shard_parts with world > 1)");
+    if (part < 0 || part >= c->shard_parts) return fail(VAMP_ERR_ARG, "vamp_sampler_scatter_put: no such part");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->shard_world * c->part_slots * (c->regions_h[0].D + 1);
+    HIP_TRY(hipMemcpyAsync(c->recv_d + (size_t)part * n, rows_all, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = launch_scatter(c, part, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return VAMP_OK;
 }
 

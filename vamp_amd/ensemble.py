@@ -1,25 +1,35 @@
-"""Walker-parallel stretch-move driver: one process per GPU, torch.distributed for the exchange.
+"""Walker-parallel stretch-move driver: one process per GPU.
 
-The ensemble of ONE region is sharded over ``world`` ranks by contiguous blocks of walkers (whole
-split chunks, so every rank moves exactly W/(2*world) walkers per half-step).  Every rank keeps
-the full position array X[W, D] on its device, because a moving walker may pick any member of
-the frozen complement as its partner.  After each half-step the ranks exchange the rows they own
-by all-gather (RCCL over xGMI when the backend is "nccl") with no host synchronisation inside
-the step loop.
+The ensemble of ONE region is sharded over ``world`` ranks by blocks of whole split chunks, so
+every rank moves exactly W/(2*world) walkers per half-step.  Every rank keeps the full state
+X[W, D] on its device, because a moving walker may pick any member of the frozen complement as
+its partner.  After a half-step only the ACTIVE colour has changed: each rank contributes the
+(W/2/world) x (D + 1) doubles its movers ended with (position + lnprob, packed in slot order by
+the half-step kernel itself), one all-gather moves them, and a scatter kernel writes them to the
+rows that hold those slots in this (step, half) -- SURVEY 8e: 1.5 MiB per GPU per half-step on
+the headline at world = 8.
 
-Overlap: a rank's share is cut into ``parts`` pieces (default 2 with RCCL).  The kernel of piece
-p + 1 runs while the all-gather of piece p is in flight on RCCL's own stream (``async_op``; the
-compute stream waits for all pieces before the next colour starts).  That is safe because a
-half-step kernel reads only rows of the frozen colour, which the in-flight gather rewrites with
-the values they already hold, and writes only its own piece.  Rows are laid out so that piece p
-of every rank lies in the p-th ``W/parts`` slab of X: each gather is in place into one contiguous
-slab (vamp_sampler_set_shard_parts).
+``exchange``:
+  "rccl"       production: the library owns an RCCL communicator (vamp_comm_init_rank) and runs
+               pack -> ncclAllGather -> scatter on its own HIP streams inside
+               vamp_sampler_half_step / vamp_sampler_run_dev; nothing here touches the data path
+               and there is no host synchronisation inside the step loop.  ``dist`` (a
+               torch.distributed process group, any backend) is used ONCE, to hand rank 0's
+               128-byte communicator id to the other ranks.
+  "gloo_host"  tests: the same pack and scatter kernels, with the packed rows staged through host
+               memory and all-gathered by ``dist`` (lets two ranks share one GPU, and lets the
+               host logic run against an oracle-backed stand-in on CPU).
+  "none"       single rank.
 
-Independent regions (BASELINE.json config 3) need no exchange at all: give each rank its own
-``HipContext`` with a subset of the regions.
+Overlap: a rank's share can be cut into ``parts`` pieces; the exchange of piece p runs on the
+library's communication stream while the kernel of piece p + 1 computes.  Safe because a
+half-step kernel reads only rows of the frozen colour and writes only its own piece, while the
+scatter of piece p writes only rows of the moving colour of piece p.
+
+Independent regions (BASELINE.json config 3) need no exchange at all: see ``shard_regions``.
 
 Counter-based draws are keyed by (seed, step, half, global walker id) and the red/blue split by
-(seed, step, chunk), so the trajectory is bit-identical for every ``world``
+(seed, step, chunk), so the trajectory is bit-identical for every ``world`` and ``parts``
 (tests/test_distributed.py).
 """
 from __future__ import annotations
@@ -29,25 +39,38 @@ import os
 import numpy as np
 
 
+def shard_regions(costs, world):
+    """Longest-processing-time assignment of independent regions to ``world`` ranks.
+    ``costs[r]`` ~ W_r * P_r * K_r (SURVEY 8e "Multi-region (C3)": no collective, balance by the
+    sum).  Returns a list of ``world`` sorted index lists; every rank computes the same answer."""
+    costs = np.asarray(costs, dtype=np.float64)
+    order = np.argsort(-costs, kind="stable")
+    load = np.zeros(world)
+    out = [[] for _ in range(world)]
+    for r in order:
+        g = int(np.argmin(load))          # ties: lowest rank
+        out[g].append(int(r))
+        load[g] += costs[r]
+    return [sorted(v) for v in out]
+
+
 class ShardedEnsemble:
-    """Drive a single-region sampler whose walkers are sharded over ``dist`` ranks.
+    """Drive a single-region sampler whose walkers are sharded over the ranks of ``dist``.
 
     ``backend`` is a ``HipContext`` (or, in the CPU tests of the host logic, any object with the
-    same ``sampler_*``/``half_step``/``get_state`` surface).  ``exchange``:
-      "nccl"       in-place all_gather_into_tensor on device memory (production)
-      "gloo_host"  stage the owned rows through host memory and a gloo all-gather (lets two
-                   ranks share one GPU in tests; also the CPU-only rehearsal path)
-    """
+    same ``sampler_*`` / ``half_step_part`` / ``pack_get`` / ``scatter_put`` surface)."""
 
-    def __init__(self, backend, theta0, seed, a=2.0, split_block=None, dist=None, exchange="nccl", torch_device=None,
-                 torch_state=None, exchange_single_rank=False, parts=None):
+    def __init__(self, backend, theta0, seed, a=2.0, split_block=None, dist=None, exchange="rccl", parts=None,
+                 exchange_single_rank=False):
         self.backend = backend
         self.dist = dist
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         # exchange_single_rank: keep the collective in the loop even for one rank (rehearses the
         # RCCL call pattern on a one-GPU box; the gather is then a self-copy)
-        self.exchange = exchange if (self.world > 1 or (exchange_single_rank and dist is not None)) else "none"
+        self.exchange = exchange if (self.world > 1 or exchange_single_rank) else "none"
+        if self.exchange not in ("rccl", "gloo_host", "none"):
+            raise ValueError("exchange must be 'rccl', 'gloo_host' or 'none'")
         theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
         self.W, self.D = theta0.shape
         if split_block is None:
@@ -57,30 +80,20 @@ class ShardedEnsemble:
             raise ValueError("W/split_block must be a multiple of the number of ranks")
         self.split_block = split_block
         if parts is None:
-            parts = int(os.environ.get("VAMP_EXCHANGE_PARTS", "0")) or (2 if self.exchange == "nccl" else 1)
+            parts = int(os.environ.get("VAMP_EXCHANGE_PARTS", "0")) or (2 if self.exchange == "rccl" else 1)
             while parts > 1 and (self.W // split_block) % (self.world * parts):
                 parts -= 1
         if parts < 1 or (self.W // split_block) % (self.world * parts):
             raise ValueError("W/split_block must be a multiple of ranks * parts")
         self.parts = parts
-        self._torch = None
-        self._X_t = None
-        if torch_state is None:
-            torch_state = self.exchange == "nccl"
-        if self.exchange == "nccl" and not torch_state:
-            raise ValueError("the nccl exchange needs the state in torch tensors")
-        if torch_state:
-            import torch
-            self._torch = torch
-            dev = torch_device if torch_device is not None else torch.device("cuda", torch.cuda.current_device())
-            # state lives in torch tensors so that RCCL can address it; the library adopts the
-            # pointers and torch's current stream
-            self._X_t = torch.empty(self.W * self.D, dtype=torch.float64, device=dev)
-            self._lnp_t = torch.empty(self.W, dtype=torch.float64, device=dev)
-            backend.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-            backend.sampler_bind_state(self._X_t.data_ptr(), self._lnp_t.data_ptr())
+        if self.exchange == "rccl":
+            from .hip_backend import comm_unique_id
+            box = [comm_unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0)        # 128 bytes over the bootstrap group
+            backend.comm_init_rank(box[0], self.rank, self.world)
         backend.sampler_init(theta0, seed=seed, a=a, split_block=split_block)
-        if self.world > 1 or self.parts > 1:
+        if self.world > 1 or self.parts > 1 or self.exchange == "rccl":
             self.own_ranges = backend.sampler_set_shard_parts(self.rank, self.world, self.parts)
         else:
             self.own_ranges = [(0, self.W)]
@@ -89,72 +102,52 @@ class ShardedEnsemble:
         self.own_mask = np.zeros(self.W, dtype=bool)
         for b, e in self.own_ranges:
             self.own_mask[b:e] = True
-        if torch_state:
-            self._X2d = self._X_t.view(self.W, self.D)
-            slab = self.W // self.parts
-            self._slabs = [self._X2d[p * slab:(p + 1) * slab] for p in range(self.parts)]
-            self._own = [self._X2d[b:e] for b, e in self.own_ranges]
         self.steps_done = 0
 
-    # exchange of piece p of the rows this rank owns; returns a work handle or None
-    def _all_gather(self, p):
-        if self.exchange == "none":
-            return None
-        if self.exchange == "nccl":
-            return self.dist.all_gather_into_tensor(self._slabs[p], self._own[p], async_op=True)
+    def _exchange_host(self, p):
+        """piece p: packed movers of every rank through host memory and ``dist``"""
         import torch
-        X, lnp, nacc, step = self.backend.get_state()
-        b, e = self.own_ranges[p]
-        slab = self.W // self.parts
-        mine = torch.from_numpy(np.ascontiguousarray(X[b:e]))
-        full = torch.empty((slab, self.D), dtype=torch.float64)
+        mine = torch.from_numpy(np.ascontiguousarray(self.backend.pack_get(p)))
+        full = torch.empty((self.world * mine.shape[0], mine.shape[1]), dtype=torch.float64)
         self.dist.all_gather_into_tensor(full, mine)
-        X[p * slab:(p + 1) * slab] = full.numpy()
-        # lnprob of foreign walkers is never read by this rank; keep the local values
-        self.backend.set_state(X, lnp, step)
-        return None
+        self.backend.scatter_put(p, full.numpy())
 
     def step(self, n_steps=1):
         for _ in range(n_steps):
             for half in (0, 1):
-                pending = []
-                for p in range(self.parts):
-                    if self.parts == 1:
-                        self.backend.half_step(half)
-                    else:
+                if self.exchange == "gloo_host":
+                    for p in range(self.parts):
                         self.backend.half_step_part(half, p)
-                    w = self._all_gather(p)
-                    if w is not None:
-                        pending.append(w)
-                for w in pending:
-                    w.wait()          # the compute stream waits; the host does not
+                        self._exchange_host(p)
+                else:                                       # "rccl": the library exchanges; "none": nothing to do
+                    self.backend.half_step(half)
             self.steps_done += 1
 
+    def run_dev(self, n_steps, thin=1, chain_ptr=None, lnprob_ptr=None):
+        """The whole loop in one library call (production path; chain kept on the device)."""
+        if self.exchange == "gloo_host":
+            raise ValueError("the host-staged exchange is stepped from Python (step())")
+        sec = self.backend.run_dev(n_steps, thin=thin, chain_ptr=chain_ptr, lnprob_ptr=lnprob_ptr)
+        self.steps_done += n_steps
+        return sec
+
     def synchronize(self):
-        if self._torch is not None:
-            self._torch.cuda.synchronize()
-        elif hasattr(self.backend, "synchronize"):
+        if hasattr(self.backend, "synchronize"):
             self.backend.synchronize()
 
     def gather_state(self):
-        """Full (X[W,D], lnp[W], n_accept[W]) on every rank (lnp / n_accept are only valid on
-        their owner, so they are exchanged here, outside the step loop)."""
+        """Full (X[W,D], lnp[W], n_accept[W]) on every rank.  Positions and lnprob are complete on
+        every rank already (they travel with the exchange); n_accept is kept by the owner only and
+        is gathered here, outside the step loop."""
         X, lnp, nacc, _ = self.backend.get_state()
         if self.world == 1:
             return X, lnp, nacc
         import torch
-        outs = []
+        full_np = np.empty(self.W, dtype=np.int64)
         slab = self.W // self.parts
-        for arr, dt in ((lnp, torch.float64), (nacc, torch.int64)):
-            full_np = np.empty(self.W, dtype=arr.dtype)
-            for p, (b, e) in enumerate(self.own_ranges):
-                mine = torch.from_numpy(np.ascontiguousarray(arr[b:e]))
-                if self.exchange == "nccl":
-                    mine = mine.to(self._X_t.device)
-                    full = torch.empty(slab, dtype=dt, device=self._X_t.device)
-                else:
-                    full = torch.empty(slab, dtype=dt)
-                self.dist.all_gather_into_tensor(full, mine)
-                full_np[p * slab:(p + 1) * slab] = full.cpu().numpy()
-            outs.append(full_np)
-        return X, outs[0], outs[1]
+        for p, (b, e) in enumerate(self.own_ranges):
+            mine = torch.from_numpy(np.ascontiguousarray(nacc[b:e]))
+            full = torch.empty(slab, dtype=torch.int64)
+            self.dist.all_gather_into_tensor(full, mine)          # needs a CPU-capable (gloo) group
+            full_np[p * slab:(p + 1) * slab] = full.numpy()
+        return X, lnp, full_np

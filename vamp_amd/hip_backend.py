@@ -31,6 +31,14 @@ def device_count():
     return n.value
 
 
+def comm_unique_id():
+    """128-byte RCCL id for vamp_comm_init_rank: rank 0 creates it and sends it to the other
+    ranks over any host channel."""
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.load().vamp_comm_unique_id(buf))
+    return buf.raw
+
+
 def default_split_block(W, world=1):
     """Largest even divisor of W that is <= 1024 and keeps W/block a multiple of ``world``."""
     for b in range(min(W, 1024), 1, -1):
@@ -76,8 +84,39 @@ class HipContext:
     def set_stream(self, stream_ptr):
         _lib.check(self._lib.vamp_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def set_stream_default(self):
+        """Run on HIP's legacy default stream (what torch uses when no stream is set)."""
+        _lib.check(self._lib.vamp_ctx_set_stream_default(self._h))
+
     def synchronize(self):
         _lib.check(self._lib.vamp_ctx_synchronize(self._h))
+
+    # -- multi-GPU (walker sharding) ---------------------------------------------------------
+    def comm_init_rank(self, comm_id, rank, world):
+        """Collective: join the RCCL communicator ``comm_id`` (comm_unique_id() of rank 0) as
+        ``rank`` of ``world``; the per-half-step exchange then runs inside the library."""
+        if len(comm_id) != 128:
+            raise ValueError("comm_id must be the 128 bytes of comm_unique_id()")
+        _lib.check(self._lib.vamp_comm_init_rank(self._h, C.c_char_p(bytes(comm_id)), int(rank), int(world)))
+
+    def comm_destroy(self):
+        _lib.check(self._lib.vamp_comm_destroy(self._h))
+
+    def pack_get(self, part=0):
+        """This rank's movers of piece ``part`` after its last half-step: [slots, D + 1]
+        (position, lnprob), in slot order (host-staged exchange)."""
+        n = self._part_slots
+        out = np.empty((n, self.ndims[0] + 1))
+        _lib.check(self._lib.vamp_sampler_pack_get(self._h, int(part), _dp(out)))
+        return out
+
+    def scatter_put(self, part, rows_all):
+        """Write the movers of piece ``part`` gathered from all ranks (rank order,
+        [world * slots, D + 1]) into the state."""
+        rows_all = _f64(rows_all)
+        if rows_all.shape != (self._shard_world * self._part_slots, self.ndims[0] + 1):
+            raise ValueError("rows_all must be [world * part_slots, D + 1]")
+        _lib.check(self._lib.vamp_sampler_scatter_put(self._h, int(part), _dp(rows_all)))
 
     def set_packing(self, lanes_per_walker):
         """0 = automatic, 16 = four walkers per wavefront (<= 8 components), 64 = one walker per
@@ -218,9 +257,7 @@ class HipContext:
         self.total_walkers = W * self.n_regions
 
     def sampler_set_shard(self, rank, world):
-        b, e = C.c_int64(0), C.c_int64(0)
-        _lib.check(self._lib.vamp_sampler_set_shard(self._h, rank, world, C.byref(b), C.byref(e)))
-        return b.value, e.value
+        return self.sampler_set_shard_parts(rank, world, 1)[0]
 
     def sampler_set_shard_parts(self, rank, world, parts):
         """Cut this rank's share into ``parts`` pieces (see vamp_sampler_set_shard_parts); returns
@@ -228,6 +265,8 @@ class HipContext:
         b = (C.c_int64 * parts)()
         e = (C.c_int64 * parts)()
         _lib.check(self._lib.vamp_sampler_set_shard_parts(self._h, rank, world, parts, b, e))
+        self._shard_world = world
+        self._part_slots = (int(e[0]) - int(b[0])) // 2      # half of every owned split chunk moves per half-step
         return [(int(b[i]), int(e[i])) for i in range(parts)]
 
     def sampler_state_ptrs(self):
@@ -276,6 +315,15 @@ class HipContext:
             res["chain"] = ch[0] if self.n_regions == 1 else ch
             res["lnprob"] = lc[0] if self.n_regions == 1 else lc
         return res
+
+    def run_dev(self, n_steps, thin=1, chain_ptr=None, lnprob_ptr=None):
+        """n_steps with the chain written to caller-owned DEVICE memory (raw pointers, e.g.
+        ``tensor.data_ptr()``): chain [n_keep, total_theta], lnprob [n_keep, total_walkers].
+        Returns the seconds spent in the sampling loop."""
+        sec = C.c_double(0.0)
+        _lib.check(self._lib.vamp_sampler_run_dev(self._h, int(n_steps), int(thin), C.c_void_p(chain_ptr or 0),
+                                                  C.c_void_p(lnprob_ptr or 0), C.byref(sec)))
+        return sec.value
 
     def get_state(self):
         th = np.empty(self.total_theta)
