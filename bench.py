@@ -345,7 +345,7 @@ def main():
         try:      # counters of this same command from the committed PMC passes (tools/pmc.sh; separate runs)
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             c = pj["config"]
-            if (c["pixels"], c["components"], c["walkers"], c["ndim"], c["n_gpus"], c["dtype"]) == (P, K, W, D, world, args.dtype):
+            if dist is None and (c["pixels"], c["components"], c["walkers"], c["ndim"], c["n_gpus"], c["dtype"]) == (P, K, W, D, world, args.dtype):
                 traffic = (2.0 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024.0
                 valu_instr = pj.get("SQ_INSTS_VALU_per_launch")
                 pmc_src = pj.get("source")
