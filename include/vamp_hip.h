@@ -69,15 +69,21 @@ int vamp_ctx_destroy(vamp_ctx* ctx);
 int vamp_ctx_set_stream(vamp_ctx* ctx, void* hip_stream);
 int vamp_ctx_set_stream_default(vamp_ctx* ctx);
 int vamp_ctx_synchronize(vamp_ctx* ctx);
-/* Lanes that serve one walker: 64 (one walker per wavefront), 256 (one walker per 4-wavefront
- * workgroup: each wavefront sweeps every 4th 256-pixel tile and, in fp64, the line cores are read
- * from per-line Taylor tables shared by the workgroup; long regions), 16 (four walkers per
- * wavefront, <= 8 components per region; the 9..478-pixel regions of real spectra) or 0 = choose:
- * 16 when every region has <= 8 components and the mean region is <= 128 pixels; else 256 when
- * every region has >= 2048 pixels; else 64.  The choice never depends on the number of walkers
- * in a launch, so a shard of an ensemble runs the arithmetic of the whole ensemble.  Takes
- * effect at the next vamp_set_regions.  All shapes agree to rounding (fp32: 64 and 256 bit for
- * bit). */
+/* Lanes that serve one walker:
+ *   64   one walker per wavefront;
+ *   256  one walker per 4-wavefront workgroup: each wavefront sweeps every 4th 256-pixel tile and, in
+ *        fp64, the line cores are read from per-line Taylor tables shared by the workgroup (long regions);
+ *   16   four walkers per wavefront, <= 8 components per region (the short single-line regions of
+ *        real spectra; draws come from a one-thread-per-mover launch);
+ *   65   64 lanes + the walker's own Taylor tables, <= 8 components, no far field (the blended
+ *        regions of real spectra: a few lines over a few hundred pixels);
+ *   0    choose: contexts that look like a real spectrum (<= 8 components everywhere, mean region
+ *        <= 128 pixels) are split into two launch classes -- regions with >= 3 components over >= 96
+ *        pixels run as 65, the rest as 16 (64 in launches of fewer than 16 384 walkers); otherwise
+ *        256 when every region has >= 2048 pixels, else 64.
+ * The choice never depends on how an ensemble is sharded, so a shard runs the arithmetic of the
+ * whole ensemble.  Takes effect at the next vamp_set_regions.  All shapes agree to rounding (fp32:
+ * 64 and 256 bit for bit). */
 int vamp_ctx_set_packing(vamp_ctx* ctx, int lanes_per_walker);
 
 /* Upload the data of n_regions independent absorption regions (replaces

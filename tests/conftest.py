@@ -23,10 +23,11 @@ def golden():
     return load_golden
 
 
-@pytest.fixture(scope="session", params=[0, 64, 16, 256], ids=["pack-auto", "pack-64", "pack-16", "pack-256"])
+@pytest.fixture(scope="session", params=[0, 64, 16, 256, 65], ids=["pack-auto", "pack-64", "pack-16", "pack-256", "pack-64t"])
 def hip_ctx(request):
     """fp64 / accurate-wofz context on device 0 (GPU tests only), once per walker packing:
-    automatic, one walker per wavefront, four walkers per wavefront, one walker per workgroup."""
+    automatic, one walker per wavefront, four walkers per wavefront, one walker per workgroup, one
+    walker per wavefront with its own Taylor tables (<= 8 lines)."""
     import vamp_amd
     ctx = vamp_amd.HipContext(device=0)
     ctx.set_packing(request.param)

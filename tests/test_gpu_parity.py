@@ -190,6 +190,48 @@ def test_sampler_multi_region_matches_oracle(hip_ctx):
         assert np.array_equal(res["n_accept"][ri], nacc)
 
 
+def test_mixed_launch_classes_match_oracle():
+    """A spectrum-like context under automatic packing is cut into two launch classes (short regions;
+    blends of >= 3 lines over >= 96 px with per-walker Taylor tables), each with its own launch per
+    half-step over its own region list.  lnprob, lnprob_all and the sampler chains of every region
+    against the oracle, region by region; then the same regions with four walkers per wavefront
+    forced (draws from the k_draws launch) give the same chains."""
+    import vamp_amd
+    from tools.bench_c3 import build_regions, start_walkers
+    xs, fs, ns, ks = build_regions()
+    big = [r for r in range(len(xs)) if ks[r] >= 3 and len(xs[r]) >= 96][:3]
+    small = [r for r in range(len(xs)) if ks[r] == 1][:3]
+    pick = [small[0], big[0], small[1], big[1], big[2], small[2]]            # interleaved: the lists are not contiguous
+    xs, fs, ns, ks = [xs[r] for r in pick], [fs[r] for r in pick], [ns[r] for r in pick], [ks[r] for r in pick]
+    rng = np.random.default_rng(7)
+    W = 32
+    th = [start_walkers(rng, x, k, W) for x, k in zip(xs, ks)]
+    regs = [vo.Region(x=x, flux=f, noise=n, n_comp=k, mode=vo.MODE_VOIGT4) for x, f, n, k in zip(xs, fs, ns, ks)]
+    chains = {}
+    for packing in (0, 16):
+        with vamp_amd.HipContext(device=0) as ctx:
+            ctx.set_packing(packing)
+            ctx.set_regions(xs, fs, ns, ks, mode=vamp_amd.MODE_VOIGT4)
+            la, ca = ctx.lnprob_all(th, return_chi2=True)
+            for r, reg in enumerate(regs):
+                want, wchi = vo.log_prob_batch(reg, th[r], return_chi2=True)
+                assert np.isfinite(want).all()
+                assert np.max(np.abs(la[r] - want) / np.maximum(1, np.abs(want))) <= 1e-9, (packing, r)
+                assert np.max(np.abs(ca[r] - wchi) / wchi) <= 1e-11, (packing, r)
+                l1 = ctx.lnprob(th[r], region=r)
+                assert np.array_equal(l1, la[r]), (packing, r)
+            ctx.sampler_init(th, seed=606, split_block=8)
+            res = ctx.run(4)
+            chains[packing] = res["chain"]
+            for r, reg in enumerate(regs):
+                fn = lambda q, reg=reg: vo.log_prob_batch(reg, q)
+                chain, lchain, nacc = vo.run_sampler(fn, th[r], fn(th[r]), 4, seed=606, block=8, region=r, walker_off=r * W)
+                assert np.allclose(res["chain"][r], chain, rtol=1e-10, atol=1e-12), (packing, r)
+                assert np.array_equal(res["n_accept"][r], nacc), (packing, r)
+    for r in range(len(regs)):
+        assert np.allclose(chains[0][r], chains[16][r], rtol=1e-10, atol=1e-12)
+
+
 def test_sampler_sd_mode_and_acceptance(hip_ctx):
     """Reference-form likelihood (free sd, vpfits.py:39): stored lnprob equals a fresh evaluation
     of the final positions, and the acceptance fraction is sane."""
@@ -325,7 +367,7 @@ def test_full_size_properties(hip_ctx):
     (1) batch-position independence, (2) component-permutation invariance, (3) tau is the sum of
     single-component taus, (4) a down-scaled twin agrees with the oracle."""
     from bench import make_workload
-    if hip_ctx.packing_request == 16:
+    if hip_ctx.packing_request in (16, 65):
         pytest.skip("16 components need the one-walker-per-wavefront kernels")
     wl = make_workload(P=16384, K=16, W=64, seed=20240517, nbz=False)
     hip_ctx.set_regions(wl["x"], wl["flux"], wl["noise"], 16, mode=vo.MODE_VOIGT4)
@@ -360,7 +402,7 @@ def test_bench_shape_against_oracle(hip_ctx):
     full stretch steps with the counter-based draws (identical accept decisions, positions to
     1e-10).  16 walkers x 262 144 scipy.wofz evaluations each."""
     from bench import make_workload
-    if hip_ctx.packing_request == 16:
+    if hip_ctx.packing_request in (16, 65):
         pytest.skip("16 components need the one-walker-per-wavefront kernels")
     wl = make_workload(P=16384, K=16, W=16, nbz=True)
     assert wl["D"] == 48 and wl["mode"] == vo.MODE_NBZ3
@@ -531,7 +573,7 @@ def test_random_long_regions_match_oracle(hip_ctx, seed):
     heavily damped lines, centres at the region's edge, crowded blends: every branch of the tile
     code (far-field interpolant, Taylor tables, fractions, cap, near-axis rule in the tail)
     against the oracle's scipy.wofz restatement."""
-    if hip_ctx.packing_request == 16:
+    if hip_ctx.packing_request in (16, 65):
         pytest.skip("long regions: one walker per wavefront or workgroup")
     rng = np.random.default_rng(1000 + seed)
     worst = 0.0
@@ -627,7 +669,7 @@ def test_long_region_symmetries(hip_ctx):
     centroids and widths are scaled together, and when the spectrum is mirrored (a descending
     grid).  Each transformation moves the tile boundaries relative to the lines, so the far /
     near classification, the table intervals and the interpolation nodes all change."""
-    if hip_ctx.packing_request == 16:
+    if hip_ctx.packing_request in (16, 65):
         pytest.skip("long region: one walker per wavefront or workgroup")
     from bench import make_workload
     wl = make_workload(P=4096, K=9, W=24, seed=77, nbz=False)

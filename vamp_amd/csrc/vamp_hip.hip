@@ -108,11 +108,13 @@ struct LineRec {           // per (walker, component), lives in LDS
 #define VAMP_PARTS 4
 #endif
 constexpr int PARTS = VAMP_PARTS;
-template <int LPW_, int KCAP_, bool TAIL_, int WPB_, bool SPLIT_ = false>
+template <int LPW_, int KCAP_, bool TAIL_, int WPB_, bool SPLIT_ = false, bool TABS_ = SPLIT_, bool FF_ = (LPW_ == 64)>
 struct Pack {
     static constexpr int LPW = LPW_, KCAP = KCAP_, SUBS = 64 / LPW_;
     static constexpr bool TAIL = TAIL_;     // false: every region is a whole number of full tiles
     static constexpr bool SPLIT = SPLIT_;
+    static constexpr bool TABS = TABS_;     // per-walker Taylor tables of the line cores (fp64 Voigt)
+    static constexpr bool FF = FF_;         // far-field interpolant in full tiles
     static constexpr int WPB = WPB_;        // wavefronts per workgroup
     static constexpr int THREADS = 64 * WPB_;
     static constexpr int WALKERS_PER_BLOCK = SPLIT_ ? 1 : WPB_ * SUBS;
@@ -124,6 +126,11 @@ using PackSplit = Pack<64, KMAX, true, PARTS, true>;
 using PackSplitFull = Pack<64, KMAX, false, PARTS, true>;
 // 8 walkers x 3.7 KB of LDS per 128-thread workgroup: 5 workgroups (10 waves) per CU
 using PackSmall = Pack<16, 8, true, 2>;
+// one walker per wavefront WITH its own Taylor tables (<= 8 lines: 18 KB + 3.7 KB of LDS per
+// single-wave workgroup, 7 per CU), no far field: the blended regions of real spectra (3..8 lines,
+// ~100..500 px), where every pixel lies in some line's core and the near-axis rule (~190 issue
+// slots per evaluation against ~40 through a table) is the whole cost
+using PackMid = Pack<64, 8, true, 1, false, true, false>;
 
 constexpr int FF_NODES = 16;          // Chebyshev nodes of the far-field interpolant of one tile
 #ifndef VAMP_FF_DIST
@@ -144,10 +151,10 @@ struct TileScratch {        // per wavefront: far-field working set of the tile 
 };
 // Taylor tables of the near-axis zone of every line of ONE walker (voigt_math.hpp): 36 KiB, which
 // only a workgroup that serves a single walker can afford (3 workgroups per CU).
-template <bool ON>
-struct alignas(16) LineTables { double a[ON ? KMAX * vamp::TAB_LINE : 2]; };
+template <bool ON, int KCAP = KMAX>
+struct alignas(16) LineTables { double a[ON ? KCAP * vamp::TAB_LINE : 2]; };
 template <bool F32, int MODE, class PK>
-constexpr bool use_tables() { return PK::SPLIT && !F32 && MODE != VAMP_GAUSS3; }
+constexpr bool use_tables() { return PK::TABS && !F32 && MODE != VAMP_GAUSS3; }
 
 // barrier over the lanes that stage and sweep one walker together
 template <class PK>
@@ -246,8 +253,10 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
     }
     group_barrier<PK>();
     if constexpr (TAB) {
-        // one (line, interval) pair per thread: 16 lines x 16 intervals = the 256 threads of the group
-        for (int e = 64 * part + lane; e < K * vamp::TAB_NI; e += PK::THREADS) {
+        // one (line, interval) pair per thread: 16 lines x 16 intervals = the 256 threads of a split
+        // group; a single wavefront takes its walker's pairs 64 at a time
+        constexpr int TSTEP = PK::SPLIT ? PK::THREADS : PK::LPW;
+        for (int e = PK::SPLIT ? 64 * part + lane : lane; e < K * vamp::TAB_NI; e += TSTEP) {
             const int k = e / vamp::TAB_NI, i = e % vamp::TAB_NI;
             vamp::taylor_table_row(i, L.line[k].y, L.dtab[k], L.line[k].pole, L.line[k].hy,
                                    tab + k * vamp::TAB_LINE + i * vamp::TAB_NT);
@@ -827,18 +836,27 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<
     constexpr bool TAB = use_tables<F32, MODE, PK>();
     if constexpr (F32) {
         const float* x = px.xf + R.pix_off; const float* f = px.ff + R.pix_off; const float* wt = px.wtf + R.pix_off;
-        if constexpr (VAMP_FARFIELD && PK::SUBS == 1 && MODE != VAMP_GAUSS3 && TPIX == 4)
+        if constexpr (VAMP_FARFIELD && PK::FF && MODE != VAMP_GAUSS3 && TPIX == 4)
             sweep_range_f32_ff<MODE, PK>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi);
         else if (TPIX > 1) sweep_range_f32<MODE, PK, TPIX>(R, L, x, f, wt, lane, base0, full, stride, chi);
         if constexpr (PK::TAIL || TPIX == 1)
             if (tail) sweep_range_f32<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, PK::LPW, chi);
     } else {
         const double* x = px.x + R.pix_off; const double* f = px.f + R.pix_off; const double* wt = px.wt + R.pix_off;
-        if constexpr (VAMP_FARFIELD && PK::SUBS == 1 && MODE != VAMP_GAUSS3 && TPIX == 4)
+        if constexpr (VAMP_FARFIELD && PK::FF && MODE != VAMP_GAUSS3 && TPIX == 4)
             sweep_range_ff<MODE, PK, TAB>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi, tab);
         else if (TPIX > 1) sweep_range<MODE, PK, TPIX, TAB>(R, L, x, f, wt, lane, base0, full, stride, chi, tab);
         if constexpr (PK::TAIL || TPIX == 1)
-            if (tail) sweep_range<MODE, PK, 1, TAB>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, PK::LPW, chi, tab);
+            if (tail) {
+                int from = TPIX > 1 ? full : 0;
+                if constexpr (!PK::FF && PK::LPW == 64 && TPIX == 4) {
+                    // regions of a few hundred pixels are mostly "tail": two pixels per lane while 128 remain
+                    const int pairs = from + ((R.P - from) / 128) * 128;
+                    sweep_range<MODE, PK, 2, TAB>(R, L, x, f, wt, lane, from, pairs, 128, chi, tab);
+                    from = pairs;
+                }
+                sweep_range<MODE, PK, 1, TAB>(R, L, x, f, wt, lane, from, R.P, PK::LPW, chi, tab);
+            }
     }
 }
 
@@ -907,17 +925,19 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::
 template <bool F32, int MODE, class PK>
 __global__ __launch_bounds__(PK::THREADS, 3) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
                                                   long long W, const double* __restrict__ theta,
-                                                  double* __restrict__ lnprob, double* __restrict__ chi2) {
-    // region < 0: every region in one launch (blockIdx.y = region); theta holds the regions' [W, D_r]
-    // blocks one after the other, lnprob / chi2 are [n_regions, W]
+                                                  double* __restrict__ lnprob, double* __restrict__ chi2,
+                                                  const int* __restrict__ region_list) {
+    // region < 0: several regions in one launch (blockIdx.y indexes region_list, or the regions
+    // themselves when it is null); theta holds the regions' [W, D_r] blocks one after the other
+    // (block r starts at W * d_before(r)), lnprob / chi2 are [n_regions, W]
     const bool all = region < 0;
-    if (all) region = blockIdx.y;
+    if (all) region = region_list ? region_list[blockIdx.y] : (int)blockIdx.y;
     __shared__ WalkerLds<PK::KCAP> lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
-    __shared__ TileScratch scr[PK::WPB];
-    __shared__ double dct[FF_TABLE];
+    __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
+    __shared__ double dct[PK::FF ? FF_TABLE : 1];
     __shared__ double red[PARTS];
-    __shared__ LineTables<use_tables<F32, MODE, PK>()> tabs;
-    ff_fill_table(dct);
+    __shared__ LineTables<use_tables<F32, MODE, PK>(), PK::KCAP> tabs[PK::SPLIT ? 1 : PK::WPB];
+    if constexpr (PK::FF) ff_fill_table(dct);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
     const long long w = PK::SPLIT ? (long long)blockIdx.x : ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS + sub;
@@ -933,7 +953,8 @@ __global__ __launch_bounds__(PK::THREADS, 3) void k_lnprob(const RegionDev* __re
         for (int d = l; d < R.D; d += PK::LPW) L.theta[d] = theta[w * R.D + d];
     group_barrier<PK>();
     double chi;
-    const double v = wave_lnprob<F32, MODE, PK>(R, L, scr[wave], dct, px, l, &chi, wave, red, tabs.a);
+    const double v = wave_lnprob<F32, MODE, PK>(R, L, scr[PK::FF ? wave : 0], dct, px, l, &chi, wave, red,
+                                                tabs[PK::SPLIT ? 0 : wave].a);
     if (PK::SPLIT && wave != 0) return;
     if (l == 0) {
         lnprob[w] = v;
@@ -1062,28 +1083,82 @@ struct SamplerDev {
     double* lnp;                 // [n_regions * W]
     long long* n_accept;         // [n_regions * W]
     long long slot_begin, slot_end;   // this ctx's share of the n_regions*W/2 active slots
+    const int* region_list;      // this launch's regions (a launch class of the ctx), or nullptr = all, in order
     double* pack;                // walker-sharded runs: [slot - slot_begin][D + 1] = the mover's row and lnprob
                                  // after the accept step (what the other devices need), else nullptr
 };
 
+// The draws of one mover: which walker holds active slot `a_loc` of `region` in this (step, half),
+// its stretch factor, its partner from the frozen colour and log(u2) for the accept test.
+struct MoveDraw { long long ws, wc; double z, logu; };
+__device__ __forceinline__ MoveDraw draw_move(const SamplerDev& S, unsigned step, int half, int region, long long a_loc) {
+    const long long halfW = S.W >> 1;
+    const unsigned hb = (unsigned)(S.split_block >> 1);
+    const unsigned chunk = (unsigned)(a_loc / hb);
+    const unsigned pos = (unsigned)(a_loc % hb);
+    MoveDraw d;
+    d.ws = (long long)chunk * S.split_block +
+           split_perm(S.seed, step, chunk, (unsigned)region, pos + (half ? hb : 0u), (unsigned)S.split_block);
+    const long long gid = S.regions[region].walker_off + d.ws;
+    const unsigned k0 = (unsigned)S.seed, k1 = (unsigned)(S.seed >> 32);
+    const U4 r = philox4x32_10({(unsigned)gid, step, ((unsigned)half << 8) | STREAM_MOVE, (unsigned)(gid >> 32)}, k0, k1);
+    const double u1 = u53(r.c0, r.c1);
+    const double t = (S.a - 1.0) * u1 + 1.0;
+    d.z = t * t / S.a;
+    const unsigned long long j = __umul64hi(((unsigned long long)r.c2 << 32) | r.c3, (unsigned long long)halfW);
+    const unsigned cchunk = (unsigned)(j / hb);
+    const unsigned cpos = (unsigned)(j % hb);
+    d.wc = (long long)cchunk * S.split_block +
+           split_perm(S.seed, step, cchunk, (unsigned)region, cpos + (half ? 0u : hb), (unsigned)S.split_block);
+    const U4 r2 = philox4x32_10({(unsigned)gid, step, ((unsigned)half << 8) | STREAM_ACCEPT, (unsigned)(gid >> 32)}, k0, k1);
+    const double u2 = u53(r2.c0, r2.c1);
+    d.logu = u2 > 0.0 ? log(u2) : NEG_INF;
+    return d;
+}
+
+// Draws of a whole launch, one THREAD per mover.  A wavefront that serves one walker computes its
+// draws on the scalar unit for free; packed four to a wavefront the same integer arithmetic runs
+// on the vector unit with 4 distinct values in 64 lanes (~550 of ~1300 fixed instructions per
+// wavefront, measured through profiles/r02_a_config3_pmc_summary.txt) -- so packed launches draw
+// here, 64 distinct movers per instruction, and the half-step kernel reads the result.
+__global__ __launch_bounds__(256) void k_draws(SamplerDev S, unsigned step, int half, long long n, int* __restrict__ ws,
+                                               int* __restrict__ wc, double* __restrict__ z, double* __restrict__ logu,
+                                               double* __restrict__ logz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long halfW = S.W >> 1;
+    const long long slot = i + S.slot_begin;
+    const int ridx = (int)(slot / halfW);
+    const int region = S.region_list ? S.region_list[ridx] : ridx;
+    const MoveDraw d = draw_move(S, step, half, region, slot - (long long)ridx * halfW);
+    ws[i] = (int)d.ws;
+    wc[i] = (int)d.wc;
+    z[i] = d.z;
+    logu[i] = d.logu;
+    logz[i] = log(d.z);
+}
+
 // One half-step of the stretch move, one wavefront per active walker.
-//   EXT = draws supplied by the host (deterministic-parity hook); else Philox in-kernel.
+//   DRAWS = DRAW_INLINE: Philox in-kernel; DRAW_HOST: every draw supplied by the host for ONE region
+//   (deterministic-parity hook); DRAW_PRE: read from the arrays k_draws filled for this launch.
 // 3 waves per SIMD (<= 168 VGPRs): the far-field path is latency-bound in places (LDS round trips);
 // measured 6.94 -> 6.49 ms against the allocator's unconstrained 182 VGPRs / 2 waves
 #ifndef VAMP_MIN_WAVES
 #define VAMP_MIN_WAVES 3
 #endif
-template <bool F32, bool EXT, int MODE, class PK>
+constexpr int DRAW_INLINE = 0, DRAW_HOST = 1, DRAW_PRE = 2;
+template <bool F32, int DRAWS, int MODE, class PK>
 __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
                                                      long long ext_n, const int* __restrict__ ext_active,
                                                      const int* __restrict__ ext_partner, const double* __restrict__ ext_z,
-                                                     const double* __restrict__ ext_logu) {
+                                                     const double* __restrict__ ext_logu, const double* __restrict__ ext_logz) {
+    constexpr bool EXT = DRAWS == DRAW_HOST;
     __shared__ WalkerLds<PK::KCAP> lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
-    __shared__ TileScratch scr[PK::WPB];
-    __shared__ double dct[FF_TABLE];
+    __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
+    __shared__ double dct[PK::FF ? FF_TABLE : 1];
     __shared__ double red[PARTS];
-    __shared__ LineTables<use_tables<F32, MODE, PK>()> tabs;
-    ff_fill_table(dct);
+    __shared__ LineTables<use_tables<F32, MODE, PK>(), PK::KCAP> tabs[PK::SPLIT ? 1 : PK::WPB];
+    if constexpr (PK::FF) ff_fill_table(dct);
     const int lane = threadIdx.x & 63;
     // the wave index is the same in every lane: say so, and the draws below (Philox rounds, the
     // split bijection -- all integer) run on the scalar unit when a wave serves one walker
@@ -1095,37 +1170,25 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
     long long slot = slot0 + sub;
     int region;
     long long ws, wc;            // local walker ids (within the region) of mover and partner
-    double z, logu;
-    if (EXT) {
+    double z, logu, logz = 0.0;
+    if constexpr (DRAWS == DRAW_HOST) {
         if (slot >= ext_n) return;
         region = ext_region;
         ws = ext_active[slot]; wc = ext_partner[slot]; z = ext_z[slot]; logu = ext_logu[slot];
     } else {
+        const long long i = slot;                     // index inside this launch
         slot += S.slot_begin;
         if (slot >= S.slot_end) return;
         // every walker of a wave lies in one region (the host packs only when W/2 and the shard
         // boundaries are multiples of SUBS): keep the region description in scalar registers
-        region = __builtin_amdgcn_readfirstlane((int)((slot0 + S.slot_begin) / halfW));
-        const long long a_loc = slot - (long long)region * halfW;          // active slot inside the region
-        const unsigned hb = (unsigned)(S.split_block >> 1);
-        const unsigned chunk = (unsigned)(a_loc / hb);
-        const unsigned pos = (unsigned)(a_loc % hb);
-        ws = (long long)chunk * S.split_block +
-             split_perm(S.seed, step, chunk, (unsigned)region, pos + (half ? hb : 0u), (unsigned)S.split_block);
-        const long long gid = S.regions[region].walker_off + ws;
-        const unsigned k0 = (unsigned)S.seed, k1 = (unsigned)(S.seed >> 32);
-        const U4 r = philox4x32_10({(unsigned)gid, step, ((unsigned)half << 8) | STREAM_MOVE, (unsigned)(gid >> 32)}, k0, k1);
-        const double u1 = u53(r.c0, r.c1);
-        const double t = (S.a - 1.0) * u1 + 1.0;
-        z = t * t / S.a;
-        const unsigned long long j = __umul64hi(((unsigned long long)r.c2 << 32) | r.c3, (unsigned long long)halfW);
-        const unsigned cchunk = (unsigned)(j / hb);
-        const unsigned cpos = (unsigned)(j % hb);
-        wc = (long long)cchunk * S.split_block +
-             split_perm(S.seed, step, cchunk, (unsigned)region, cpos + (half ? 0u : hb), (unsigned)S.split_block);
-        const U4 r2 = philox4x32_10({(unsigned)gid, step, ((unsigned)half << 8) | STREAM_ACCEPT, (unsigned)(gid >> 32)}, k0, k1);
-        const double u2 = u53(r2.c0, r2.c1);
-        logu = u2 > 0.0 ? log(u2) : NEG_INF;
+        const int ridx = __builtin_amdgcn_readfirstlane((int)((slot0 + S.slot_begin) / halfW));
+        region = __builtin_amdgcn_readfirstlane(S.region_list ? S.region_list[ridx] : ridx);
+        if constexpr (DRAWS == DRAW_PRE) {
+            ws = ext_active[i]; wc = ext_partner[i]; z = ext_z[i]; logu = ext_logu[i]; logz = ext_logz[i];
+        } else {
+            const MoveDraw d = draw_move(S, step, half, region, slot - (long long)ridx * halfW);
+            ws = d.ws; wc = d.wc; z = d.z; logu = d.logu;
+        }
     }
     const RegionDev R = S.regions[region];
     WalkerLds<PK::KCAP>& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
@@ -1137,11 +1200,13 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
             L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
         }
     group_barrier<PK>();
-    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, scr[wave], dct, px, l, nullptr, wave, red, tabs.a);
+    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, scr[PK::FF ? wave : 0], dct, px, l, nullptr, wave, red,
+                                                    tabs[PK::SPLIT ? 0 : wave].a);
     if (PK::SPLIT && wave != 0) return;     // the group's first wave carries out the accept step
     const long long wg = R.walker_off + ws;
     const double lnp_s = S.lnp[wg];
-    const double diff = (double)(R.D - 1) * log(z) + lnp_q - lnp_s;
+    if constexpr (DRAWS != DRAW_PRE) logz = log(z);
+    const double diff = (double)(R.D - 1) * logz + lnp_q - lnp_s;
     const bool accept = logu < diff;                      // false for NaN
     if (!EXT && S.pack) {
         // active-colour exchange: the row this walker ends the half-step with, in slot order
@@ -1213,14 +1278,35 @@ struct DevBuf {
         else { constexpr int M = VAMP_NBZ3; __VA_ARGS__; }                      \
     } while (0)
 #define VAMP_FOR_MODE(mode, ...) VAMP_FOR_MODE_(mode, __VA_ARGS__)
-#define VAMP_FOR_MODE_PK(mode, small, split, ...)                                      \
+// launch shapes (see struct Pack): what one launch class of a context runs
+enum Shape { SH_SMALL = 0, SH_MID = 1, SH_WIDE = 2, SH_WIDE_FULL = 3, SH_SPLIT = 4, SH_SPLIT_FULL = 5 };
+#define VAMP_FOR_MODE_PK(mode, shape, ...)                                              \
     do {                                                                        \
-        if (small) { using PK = PackSmall; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
-        else if (split && c->full_tiles) { using PK = PackSplitFull; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
-        else if (split) { using PK = PackSplit; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
-        else if (c->full_tiles) { using PK = PackWideFull; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        if ((shape) == SH_SMALL) { using PK = PackSmall; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        else if ((shape) == SH_MID) { using PK = PackMid; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        else if ((shape) == SH_SPLIT_FULL) { using PK = PackSplitFull; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        else if ((shape) == SH_SPLIT) { using PK = PackSplit; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        else if ((shape) == SH_WIDE_FULL) { using PK = PackWideFull; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else { using PK = PackWide; VAMP_FOR_MODE_(mode, __VA_ARGS__); }        \
     } while (0)
+inline long long shape_walkers_per_block(int sh) {
+    return sh == SH_SMALL ? PackSmall::WALKERS_PER_BLOCK : sh == SH_MID ? PackMid::WALKERS_PER_BLOCK
+           : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? 1 : PackWide::WALKERS_PER_BLOCK;
+}
+inline unsigned shape_threads(int sh) {
+    return sh == SH_SMALL ? PackSmall::THREADS : sh == SH_MID ? PackMid::THREADS
+           : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? PackSplit::THREADS : PackWide::THREADS;
+}
+
+// A launch class: the regions of a context that one kernel shape serves.  Real spectra mix many
+// short single-line regions (four walkers per wavefront) with a few long blends (a wavefront per
+// walker with Taylor tables); each class is one launch per half-step over its own region list.
+enum ClassKind { CK_SMALL = 0, CK_MID = 1, CK_WIDE = 2 };
+struct LaunchClass {
+    int kind = CK_WIDE;
+    std::vector<int> regions;
+    int* list_d = nullptr;       // device copy of `regions`; nullptr when the class is every region in order
+};
 
 }  // namespace
 
@@ -1236,8 +1322,13 @@ struct vamp_ctx {
     int mode = VAMP_VOIGT4;
     int packing = 0;       // requested: 0 = auto, 16 or 64 lanes per walker, 256 = a 4-wave workgroup per walker
     int min_tiles = 0;     // full 256-pixel tiles of the shortest region
-    bool packed = false;   // regions qualify for <16, 8> (every K <= 8, short regions)
     bool full_tiles = false;   // every region's pixel count is a multiple of 64 * TPIX
+    std::vector<LaunchClass> classes;      // partition of the regions by kernel shape (vamp_set_regions)
+    std::vector<int> class_of;             // region -> index into classes
+    // draws of packed launches (k_draws), grown on demand
+    int *dr_ws = nullptr, *dr_wc = nullptr;
+    double *dr_z = nullptr, *dr_lu = nullptr, *dr_lz = nullptr;
+    long long dr_cap = 0;
     std::vector<RegionDev> regions_h;
     RegionDev* regions_d = nullptr;
     long long n_pix = 0;
@@ -1289,6 +1380,10 @@ int free_regions(vamp_ctx* c) {
     for (void* p : {(void*)c->regions_d, (void*)c->x_d, (void*)c->f_d, (void*)c->wt_d, (void*)c->xf_d, (void*)c->ff_d,
                     (void*)c->wtf_d})
         if (p) (void)hipFree(p);
+    for (LaunchClass& cl : c->classes)
+        if (cl.list_d) (void)hipFree(cl.list_d);
+    c->classes.clear();
+    c->class_of.clear();
     c->regions_d = nullptr;
     c->x_d = c->f_d = c->wt_d = nullptr;
     c->xf_d = c->ff_d = c->wtf_d = nullptr;
@@ -1324,13 +1419,36 @@ int flush_timing(vamp_ctx* c) {
     return 0;
 }
 
-// one walker per 4-wave workgroup?
-bool use_split(const vamp_ctx* c, long long n_walkers, bool small) {
-    if (small) return false;
-    if (c->packing == 256) return true;
-    return c->packing == 0 && c->min_tiles >= 2 * PARTS && n_walkers < SPLIT_MAX_WALKERS;
+// kernel shape of a launch of `n_walkers` walkers of class `cl`.  Never depends on the shard or
+// the entry point beyond the launch size rule of the packed shape (as in round 1: four walkers per
+// wavefront only pay off in launches that fill the chip), so a point has the same lnprob bits
+// through vamp_lnprob, vamp_lnprob_all and the sampler.
+int class_shape(const vamp_ctx* c, const LaunchClass& cl, long long n_walkers, bool packable) {
+    if (cl.kind == CK_MID) return SH_MID;
+    if (cl.kind == CK_SMALL && packable && (c->packing == 16 || n_walkers >= PACK_MIN_WALKERS)) return SH_SMALL;
+    const bool split = cl.kind == CK_WIDE && (c->packing == 256 || (c->packing == 0 && c->min_tiles >= 2 * PARTS));
+    if (split) return c->full_tiles ? SH_SPLIT_FULL : SH_SPLIT;
+    return c->full_tiles ? SH_WIDE_FULL : SH_WIDE;
 }
 
+int ensure_draw_buffers(vamp_ctx* c, long long n) {
+    if (c->dr_cap >= n) return 0;
+    for (void* p : {(void*)c->dr_ws, (void*)c->dr_wc, (void*)c->dr_z, (void*)c->dr_lu, (void*)c->dr_lz})
+        if (p) (void)hipFree(p);
+    c->dr_ws = c->dr_wc = nullptr;
+    c->dr_z = c->dr_lu = c->dr_lz = nullptr;
+    c->dr_cap = 0;
+    HIP_TRY(hipMalloc(&c->dr_ws, n * sizeof(int)));
+    HIP_TRY(hipMalloc(&c->dr_wc, n * sizeof(int)));
+    HIP_TRY(hipMalloc(&c->dr_z, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->dr_lu, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->dr_lz, n * sizeof(double)));
+    c->dr_cap = n;
+    return 0;
+}
+
+// One half-step of this ctx's share (piece `part` of it): one launch per launch class, on the ctx
+// stream.  ext: host-supplied draws for `ext_n` movers of `ext_region`.
 int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n, int part = 0) {
     SamplerDev S;
     S.regions = c->regions_d;
@@ -1342,25 +1460,13 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     S.X = c->X_d;
     S.lnp = c->lnp_d;
     S.n_accept = c->nacc_d;
-    S.slot_begin = c->slot_begin + part * c->part_stride;
-    S.slot_end = c->shard_parts > 1 ? S.slot_begin + c->part_slots : c->slot_end;
+    S.region_list = nullptr;
+    S.slot_begin = S.slot_end = 0;
     S.pack = (!ext && c->send_d) ? c->send_d + (long long)part * c->part_slots * (c->regions_h[0].D + 1) : nullptr;
     if (!ext && c->send_d) {
         c->part_step[part] = (unsigned)c->step;
         c->part_half[part] = half;
     }
-    const long long n = ext ? ext_n : (S.slot_end - S.slot_begin);
-    if (n <= 0) return 0;
-    // <16 lanes, 8 lines> packing needs every wave inside one region and one shard
-    const int subs = PackSmall::SUBS;
-    // (automatic mode packs only launches big enough to fill the chip four walkers to a wave:
-    // below that a wave per walker has the shorter critical path)
-    const bool small = c->packed && !ext && (c->W / 2) % subs == 0 && (c->split_block / 2) % subs == 0 &&
-                       (c->packing == 16 || n >= PACK_MIN_WALKERS);
-    const bool split = use_split(c, n, small);
-    const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : split ? 1 : PackWide::WALKERS_PER_BLOCK;
-    const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
-    const unsigned threads = small ? PackSmall::THREADS : split ? PackSplit::THREADS : PackWide::THREADS;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev.size()) {
@@ -1381,24 +1487,62 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     }
     const unsigned step = (unsigned)c->step;
     const PixPtrs px = c->pix();
-    if (ext) {
-        if (c->f32)
-            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_half_step<true, true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
-                                                      half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d));
-        else
-            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_half_step<false, true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
-                                                      half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d));
-    } else {
-        const int* ni = nullptr;
-        const double* nd = nullptr;
-        if (c->f32)
-            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_half_step<true, false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
-                                                      half, 0, 0ll, ni, ni, nd, nd));
-        else
-            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_half_step<false, false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, S, px, step,
-                                                      half, 0, 0ll, ni, ni, nd, nd));
+    const long long halfW = c->W / 2;
+    const int* ni = nullptr;
+    const double* nd = nullptr;
+    // <16 lanes, 8 lines> packing needs every wave inside one region and one shard
+    const int subs = PackSmall::SUBS;
+    const bool packable = !ext && halfW % subs == 0 && (c->split_block / 2) % subs == 0;
+    for (size_t ci = 0; ci < c->classes.size(); ++ci) {
+        const LaunchClass& cl = c->classes[ci];
+        if (ext && c->class_of[ext_region] != (int)ci) continue;
+        long long n;
+        if (ext) {
+            n = ext_n;
+        } else if (c->n_regions == 1) {          // possibly a shard / a piece of one
+            S.slot_begin = c->slot_begin + part * c->part_stride;
+            S.slot_end = c->shard_parts > 1 ? S.slot_begin + c->part_slots : c->slot_end;
+            n = S.slot_end - S.slot_begin;
+        } else {
+            S.slot_begin = 0;
+            S.slot_end = (long long)cl.regions.size() * halfW;
+            n = S.slot_end;
+        }
+        if (n <= 0) continue;
+        S.region_list = cl.list_d;
+        const int shape = class_shape(c, cl, n, packable);
+        const unsigned grid = (unsigned)((n + shape_walkers_per_block(shape) - 1) / shape_walkers_per_block(shape));
+        const dim3 threads(shape_threads(shape));
+        if (ext) {
+            if (c->f32)
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<true, DRAW_HOST, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
+                                                          half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d, nd));
+            else
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_HOST, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
+                                                          half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d, nd));
+        } else if (shape == SH_SMALL) {
+            // four walkers per wavefront: draws in their own one-thread-per-mover launch
+            int rc = ensure_draw_buffers(c, n);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_draws, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, S, step, half, n, c->dr_ws,
+                               c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz);
+            HIP_TRY(hipGetLastError());
+            if (c->f32)
+                VAMP_FOR_MODE_(c->mode, hipLaunchKernelGGL((k_half_step<true, DRAW_PRE, M, PackSmall>), dim3(grid), threads, 0, c->stream, S, px, step,
+                                                           half, 0, 0ll, c->dr_ws, c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz));
+            else
+                VAMP_FOR_MODE_(c->mode, hipLaunchKernelGGL((k_half_step<false, DRAW_PRE, M, PackSmall>), dim3(grid), threads, 0, c->stream, S, px, step,
+                                                           half, 0, 0ll, c->dr_ws, c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz));
+        } else {
+            if (c->f32)
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<true, DRAW_INLINE, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
+                                                          half, 0, 0ll, ni, ni, nd, nd, nd));
+            else
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_INLINE, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
+                                                          half, 0, 0ll, ni, ni, nd, nd, nd));
+        }
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
     return 0;
 }
@@ -1599,8 +1743,8 @@ int vamp_ctx_set_stream_default(vamp_ctx* c) {
 
 int vamp_ctx_set_packing(vamp_ctx* c, int lanes_per_walker) {
     if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: ctx is NULL");
-    if (lanes_per_walker != 0 && lanes_per_walker != 16 && lanes_per_walker != 64 && lanes_per_walker != 256)
-        return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: lanes_per_walker must be 0 (auto), 16, 64 or 256");
+    if (lanes_per_walker != 0 && lanes_per_walker != 16 && lanes_per_walker != 64 && lanes_per_walker != 65 && lanes_per_walker != 256)
+        return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: lanes_per_walker must be 0 (auto), 16, 64, 65 (64 + per-walker tables) or 256");
     c->packing = lanes_per_walker;
     return VAMP_OK;
 }
@@ -1710,18 +1854,39 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         int kmax = 0;
         for (int r = 0; r < n_regions; ++r) kmax = std::max(kmax, R[r].K);
         const double mean_p = (double)pix_off[n_regions] / n_regions;
-        if (c->packing == 16) {
-            if (kmax > PackSmall::KCAP) return fail(VAMP_ERR_ARG, "vamp_set_regions: 16-lane packing supports at most 8 components per region");
-            c->packed = true;
-        } else if (c->packing == 64 || c->packing == 256) {
-            c->packed = false;
-        } else {
-            c->packed = kmax <= PackSmall::KCAP && mean_p <= 128.0;
-        }
+        if ((c->packing == 16 || c->packing == 65) && kmax > PackSmall::KCAP)
+            return fail(VAMP_ERR_ARG, "vamp_set_regions: packings 16 and 65 support at most 8 components per region");
         c->full_tiles = true;
         for (int r = 0; r < n_regions; ++r) c->full_tiles = c->full_tiles && (R[r].P % (64 * TPIX) == 0);
         c->min_tiles = R[0].P / (64 * TPIX);
         for (int r = 1; r < n_regions; ++r) c->min_tiles = std::min(c->min_tiles, R[r].P / (64 * TPIX));
+        // launch classes.  Forced packings: one class.  Automatic: contexts that look like a real
+        // spectrum (<= 8 lines everywhere, mean region <= 128 px) split into the blends worth a
+        // wavefront and a set of Taylor tables per walker (>= 3 lines over >= 96 px: table building
+        // costs ~2 near-axis evaluations per line and interval, repaid from ~30 px per line on) and
+        // the rest, four walkers to a wavefront; everything else is one wide class.
+        c->class_of.assign(n_regions, 0);
+        const bool spectrum_like = c->packing == 0 && kmax <= PackSmall::KCAP && mean_p <= 128.0;
+        LaunchClass first, second;
+        first.kind = c->packing == 16 ? CK_SMALL : c->packing == 65 ? CK_MID : spectrum_like ? CK_SMALL : CK_WIDE;
+        second.kind = CK_MID;
+        for (int r = 0; r < n_regions; ++r) {
+            const bool mid = spectrum_like && R[r].K >= 3 && R[r].P >= 96 && mode != VAMP_GAUSS3 && !c->f32;
+            (mid ? second : first).regions.push_back(r);
+            c->class_of[r] = mid ? 1 : 0;
+        }
+        if (first.regions.empty()) {
+            for (int r = 0; r < n_regions; ++r) c->class_of[r] = 0;
+            c->classes.push_back(second);
+        } else {
+            c->classes.push_back(first);
+            if (!second.regions.empty()) c->classes.push_back(second);
+        }
+        if (c->classes.size() > 1)
+            for (LaunchClass& cl : c->classes) {
+                HIP_TRY(hipMalloc(&cl.list_d, cl.regions.size() * sizeof(int)));
+                HIP_TRY(hipMemcpy(cl.list_d, cl.regions.data(), cl.regions.size() * sizeof(int), hipMemcpyHostToDevice));
+            }
     }
     c->regions_h = R;
     c->mode = mode;
@@ -1738,6 +1903,30 @@ int vamp_region_ndim(vamp_ctx* c, int region, int* ndim) {
 }
 
 namespace {
+// k_lnprob on device arrays: region >= 0: theta[W, D] of that region -> lnprob[W]; region < 0: every
+// region, theta = the regions' [W, D_r] blocks one after the other -> lnprob[n_regions, W]; one launch
+// per launch class (blockIdx.y walks the class's region list)
+int launch_lnprob(vamp_ctx* c, int region, long long W, const double* th_d, double* lp_d, double* ch_d) {
+    const bool all = region < 0;
+    const bool packable = true;      // one region per block row: every wave lies inside one region
+    for (size_t ci = 0; ci < c->classes.size(); ++ci) {
+        const LaunchClass& cl = c->classes[ci];
+        if (!all && c->class_of[region] != (int)ci) continue;
+        const int shape = class_shape(c, cl, W, packable);
+        const long long per_block = shape_walkers_per_block(shape);
+        const dim3 grid((unsigned)((W + per_block - 1) / per_block), all ? (unsigned)cl.regions.size() : 1u);
+        const dim3 threads(shape_threads(shape));
+        if (c->f32)
+            VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_lnprob<true, M, PK>), grid, threads, 0, c->stream, c->regions_d, region,
+                                                      c->pix(), W, th_d, lp_d, ch_d, (const int*)cl.list_d));
+        else
+            VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_lnprob<false, M, PK>), grid, threads, 0, c->stream, c->regions_d, region,
+                                                      c->pix(), W, th_d, lp_d, ch_d, (const int*)cl.list_d));
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
 // region >= 0: W parameter vectors of that region; region < 0: W vectors of EVERY region
 int lnprob_impl(vamp_ctx* c, int region, int64_t W, const double* theta, double* lnprob, double* chi2) {
     HIP_TRY(hipSetDevice(c->device));
@@ -1762,18 +1951,8 @@ int lnprob_impl(vamp_ctx* c, int region, int64_t W, const double* theta, double*
     double *th_d = c->sc_th, *lp_d = c->sc_lp, *ch_d = chi2 ? c->sc_chi : nullptr;
     HIP_TRY(hipMemcpyAsync(th_d, theta, nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
     // (the shape must not depend on `all`: a point has the same lnprob bits through either entry)
-    const bool small = c->packed && (c->packing == 16 || W >= PACK_MIN_WALKERS);
-    const bool split = use_split(c, W, small);
-    const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : split ? 1 : PackWide::WALKERS_PER_BLOCK;
-    const dim3 grid((unsigned)((W + per_block - 1) / per_block), all ? (unsigned)c->n_regions : 1u);
-    const unsigned threads = small ? PackSmall::THREADS : split ? PackSplit::THREADS : PackWide::THREADS;
-    if (c->f32)
-        VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_lnprob<true, M, PK>), grid, dim3(threads), 0, c->stream, c->regions_d, region,
-                                                  c->pix(), (long long)W, th_d, lp_d, ch_d));
-    else
-        VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_lnprob<false, M, PK>), grid, dim3(threads), 0, c->stream, c->regions_d, region,
-                                                  c->pix(), (long long)W, th_d, lp_d, ch_d));
-    HIP_TRY(hipGetLastError());
+    int rc = launch_lnprob(c, region, W, th_d, lp_d, ch_d);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(lnprob, lp_d, nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (chi2) HIP_TRY(hipMemcpyAsync(chi2, ch_d, nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2074,22 +2253,11 @@ int vamp_sampler_init(vamp_ctx* c, int64_t W, const double* theta0, uint64_t see
     HIP_TRY(hipMalloc(&c->nacc_d, c->total_walkers * sizeof(long long)));
     HIP_TRY(hipMemsetAsync(c->nacc_d, 0, c->total_walkers * sizeof(long long), c->stream));
     HIP_TRY(hipMemcpyAsync(c->X_d, theta0, tt * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    // initial log-posteriors of every walker
-    for (int r = 0; r < c->n_regions; ++r) {
-        const RegionDev& R = c->regions_h[r];
-        const bool small = c->packed && (c->packing == 16 || W >= PACK_MIN_WALKERS);
-        const bool split = use_split(c, W, small);
-        const long long per_block = small ? PackSmall::WALKERS_PER_BLOCK : split ? 1 : PackWide::WALKERS_PER_BLOCK;
-        const unsigned grid = (unsigned)((W + per_block - 1) / per_block);
-        const unsigned threads = small ? PackSmall::THREADS : split ? PackSplit::THREADS : PackWide::THREADS;
-        double* nochi = nullptr;
-        if (c->f32)
-            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_lnprob<true, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, r,
-                                                      c->pix(), (long long)W, c->X_d + R.theta_off, c->lnp_d + R.walker_off, nochi));
-        else
-            VAMP_FOR_MODE_PK(c->mode, small, split, hipLaunchKernelGGL((k_lnprob<false, M, PK>), dim3(grid), dim3(threads), 0, c->stream, c->regions_d, r,
-                                                      c->pix(), (long long)W, c->X_d + R.theta_off, c->lnp_d + R.walker_off, nochi));
-        HIP_TRY(hipGetLastError());
+    // initial log-posteriors of every walker: the state has the layout of vamp_lnprob_all's arguments
+    // (block r at W * d_before(r), lnprob of region r at r * W), so this is one launch per launch class
+    {
+        int rc = launch_lnprob(c, -1, W, c->X_d, c->lnp_d, nullptr);
+        if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->shard_rank = 0;

@@ -120,8 +120,9 @@ class HipContext:
 
     def set_packing(self, lanes_per_walker):
         """0 = automatic, 16 = four walkers per wavefront (<= 8 components), 64 = one walker per
-        wavefront, 256 = one walker per 4-wavefront workgroup (long regions).  Applies from
-        the next set_regions call."""
+        wavefront, 65 = one walker per wavefront with its own Taylor tables (<= 8 components),
+        256 = one walker per 4-wavefront workgroup (long regions).  Applies from the next
+        set_regions call."""
         _lib.check(self._lib.vamp_ctx_set_packing(self._h, int(lanes_per_walker)))
 
     # -- data ----------------------------------------------------------------------------
