@@ -19,19 +19,19 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
   echo "pmc group $i done"
 done
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, re
 out=sys.argv[1]
-agg=collections.defaultdict(list)
-names=set()
+agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out+"/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k=row["Kernel_Name"]
-        if "k_half_step" not in k: continue
-        names.add(k.split("(")[0][:160])
-        agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        if "k_half_step" not in k and "k_draws" not in k: continue
+        m=re.search(r"(k_half_step<[^>]*Pack<[^>]*>|k_draws)", k)
+        agg[m.group(1) if m else k[:120]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(out+"/summary.txt","w") as fh:
-    for k in sorted(names): fh.write("# kernel: "+k+"\n")
-    for c,vals in sorted(agg.items()):
-        line=f"{c:28s} n={len(vals):3d} mean={sum(vals)/len(vals):.6g}"
-        print(line); fh.write(line+"\n")
+    for k in sorted(agg):
+        fh.write("# kernel: "+k+"\n"); print("# kernel:",k)
+        for c,vals in sorted(agg[k].items()):
+            line=f"{c:28s} n={len(vals):3d} mean={sum(vals)/len(vals):.6g}"
+            print(line); fh.write(line+"\n")
 PY

@@ -126,6 +126,9 @@ using PackSplit = Pack<64, KMAX, true, PARTS, true>;
 using PackSplitFull = Pack<64, KMAX, false, PARTS, true>;
 // 8 walkers x 3.7 KB of LDS per 128-thread workgroup: 5 workgroups (10 waves) per CU
 using PackSmall = Pack<16, 8, true, 2>;
+// the same for regions of one or two lines (most regions of a real spectrum): 0.9 KB instead of
+// 3.7 KB of LDS per walker, so that registers, not LDS, set the occupancy
+using PackSmall2 = Pack<16, 2, true, 2>;
 // one walker per wavefront WITH its own Taylor tables (<= 8 lines: 18 KB + 3.7 KB of LDS per
 // single-wave workgroup, 7 per CU), no far field: the blended regions of real spectra (3..8 lines,
 // ~100..500 px), where every pixel lies in some line's core and the near-axis rule (~190 issue
@@ -840,7 +843,21 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<
             sweep_range_f32_ff<MODE, PK>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi);
         else if (TPIX > 1) sweep_range_f32<MODE, PK, TPIX>(R, L, x, f, wt, lane, base0, full, stride, chi);
         if constexpr (PK::TAIL || TPIX == 1)
-            if (tail) sweep_range_f32<MODE, PK, 1>(R, L, x, f, wt, lane, TPIX > 1 ? full : 0, R.P, PK::LPW, chi);
+            if (tail) {
+                const int from = TPIX > 1 ? full : 0;
+                if constexpr (!PK::FF && TPIX == 4) {
+                    // short regions are all "tail": one iteration with just enough pixels per lane (1..4
+                    // independent evaluation chains, all pixel loads in flight together) instead of up
+                    // to four dependent one-pixel rounds
+                    const int nt = (R.P - from + PK::LPW - 1) / PK::LPW;
+                    if (nt == 4) sweep_range_f32<MODE, PK, 4>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi);
+                    else if (nt == 3) sweep_range_f32<MODE, PK, 3>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi);
+                    else if (nt == 2) sweep_range_f32<MODE, PK, 2>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi);
+                    else if (nt == 1) sweep_range_f32<MODE, PK, 1>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi);
+                } else {
+                    sweep_range_f32<MODE, PK, 1>(R, L, x, f, wt, lane, from, R.P, PK::LPW, chi);
+                }
+            }
     } else {
         const double* x = px.x + R.pix_off; const double* f = px.f + R.pix_off; const double* wt = px.wt + R.pix_off;
         if constexpr (VAMP_FARFIELD && PK::FF && MODE != VAMP_GAUSS3 && TPIX == 4)
@@ -848,14 +865,16 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<
         else if (TPIX > 1) sweep_range<MODE, PK, TPIX, TAB>(R, L, x, f, wt, lane, base0, full, stride, chi, tab);
         if constexpr (PK::TAIL || TPIX == 1)
             if (tail) {
-                int from = TPIX > 1 ? full : 0;
-                if constexpr (!PK::FF && PK::LPW == 64 && TPIX == 4) {
-                    // regions of a few hundred pixels are mostly "tail": two pixels per lane while 128 remain
-                    const int pairs = from + ((R.P - from) / 128) * 128;
-                    sweep_range<MODE, PK, 2, TAB>(R, L, x, f, wt, lane, from, pairs, 128, chi, tab);
-                    from = pairs;
+                const int from = TPIX > 1 ? full : 0;
+                if constexpr (!PK::FF && TPIX == 4) {
+                    const int nt = (R.P - from + PK::LPW - 1) / PK::LPW;      // see the fp32 branch
+                    if (nt == 4) sweep_range<MODE, PK, 4, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab);
+                    else if (nt == 3) sweep_range<MODE, PK, 3, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab);
+                    else if (nt == 2) sweep_range<MODE, PK, 2, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab);
+                    else if (nt == 1) sweep_range<MODE, PK, 1, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab);
+                } else {
+                    sweep_range<MODE, PK, 1, TAB>(R, L, x, f, wt, lane, from, R.P, PK::LPW, chi, tab);
                 }
-                sweep_range<MODE, PK, 1, TAB>(R, L, x, f, wt, lane, from, R.P, PK::LPW, chi, tab);
             }
     }
 }
@@ -1279,10 +1298,11 @@ struct DevBuf {
     } while (0)
 #define VAMP_FOR_MODE(mode, ...) VAMP_FOR_MODE_(mode, __VA_ARGS__)
 // launch shapes (see struct Pack): what one launch class of a context runs
-enum Shape { SH_SMALL = 0, SH_MID = 1, SH_WIDE = 2, SH_WIDE_FULL = 3, SH_SPLIT = 4, SH_SPLIT_FULL = 5 };
+enum Shape { SH_SMALL = 0, SH_MID = 1, SH_WIDE = 2, SH_WIDE_FULL = 3, SH_SPLIT = 4, SH_SPLIT_FULL = 5, SH_SMALL2 = 6 };
 #define VAMP_FOR_MODE_PK(mode, shape, ...)                                              \
     do {                                                                        \
         if ((shape) == SH_SMALL) { using PK = PackSmall; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        else if ((shape) == SH_SMALL2) { using PK = PackSmall2; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else if ((shape) == SH_MID) { using PK = PackMid; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else if ((shape) == SH_SPLIT_FULL) { using PK = PackSplitFull; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else if ((shape) == SH_SPLIT) { using PK = PackSplit; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
@@ -1290,18 +1310,18 @@ enum Shape { SH_SMALL = 0, SH_MID = 1, SH_WIDE = 2, SH_WIDE_FULL = 3, SH_SPLIT =
         else { using PK = PackWide; VAMP_FOR_MODE_(mode, __VA_ARGS__); }        \
     } while (0)
 inline long long shape_walkers_per_block(int sh) {
-    return sh == SH_SMALL ? PackSmall::WALKERS_PER_BLOCK : sh == SH_MID ? PackMid::WALKERS_PER_BLOCK
+    return (sh == SH_SMALL || sh == SH_SMALL2) ? PackSmall::WALKERS_PER_BLOCK : sh == SH_MID ? PackMid::WALKERS_PER_BLOCK
            : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? 1 : PackWide::WALKERS_PER_BLOCK;
 }
 inline unsigned shape_threads(int sh) {
-    return sh == SH_SMALL ? PackSmall::THREADS : sh == SH_MID ? PackMid::THREADS
+    return (sh == SH_SMALL || sh == SH_SMALL2) ? PackSmall::THREADS : sh == SH_MID ? PackMid::THREADS
            : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? PackSplit::THREADS : PackWide::THREADS;
 }
 
 // A launch class: the regions of a context that one kernel shape serves.  Real spectra mix many
 // short single-line regions (four walkers per wavefront) with a few long blends (a wavefront per
 // walker with Taylor tables); each class is one launch per half-step over its own region list.
-enum ClassKind { CK_SMALL = 0, CK_MID = 1, CK_WIDE = 2 };
+enum ClassKind { CK_SMALL = 0, CK_MID = 1, CK_WIDE = 2, CK_SMALL2 = 3 };
 struct LaunchClass {
     int kind = CK_WIDE;
     std::vector<int> regions;
@@ -1425,7 +1445,8 @@ int flush_timing(vamp_ctx* c) {
 // through vamp_lnprob, vamp_lnprob_all and the sampler.
 int class_shape(const vamp_ctx* c, const LaunchClass& cl, long long n_walkers, bool packable) {
     if (cl.kind == CK_MID) return SH_MID;
-    if (cl.kind == CK_SMALL && packable && (c->packing == 16 || n_walkers >= PACK_MIN_WALKERS)) return SH_SMALL;
+    if ((cl.kind == CK_SMALL || cl.kind == CK_SMALL2) && packable && (c->packing == 16 || n_walkers >= PACK_MIN_WALKERS))
+        return cl.kind == CK_SMALL2 ? SH_SMALL2 : SH_SMALL;
     const bool split = cl.kind == CK_WIDE && (c->packing == 256 || (c->packing == 0 && c->min_tiles >= 2 * PARTS));
     if (split) return c->full_tiles ? SH_SPLIT_FULL : SH_SPLIT;
     return c->full_tiles ? SH_WIDE_FULL : SH_WIDE;
@@ -1520,7 +1541,7 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
             else
                 VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_HOST, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
                                                           half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d, nd));
-        } else if (shape == SH_SMALL) {
+        } else if (shape == SH_SMALL || shape == SH_SMALL2) {
             // four walkers per wavefront: draws in their own one-thread-per-mover launch
             int rc = ensure_draw_buffers(c, n);
             if (rc) return rc;
@@ -1528,11 +1549,11 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
                                c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz);
             HIP_TRY(hipGetLastError());
             if (c->f32)
-                VAMP_FOR_MODE_(c->mode, hipLaunchKernelGGL((k_half_step<true, DRAW_PRE, M, PackSmall>), dim3(grid), threads, 0, c->stream, S, px, step,
-                                                           half, 0, 0ll, c->dr_ws, c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz));
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<true, DRAW_PRE, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
+                                                          half, 0, 0ll, c->dr_ws, c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz));
             else
-                VAMP_FOR_MODE_(c->mode, hipLaunchKernelGGL((k_half_step<false, DRAW_PRE, M, PackSmall>), dim3(grid), threads, 0, c->stream, S, px, step,
-                                                           half, 0, 0ll, c->dr_ws, c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz));
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_PRE, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
+                                                          half, 0, 0ll, c->dr_ws, c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz));
         } else {
             if (c->f32)
                 VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<true, DRAW_INLINE, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
@@ -1867,21 +1888,23 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         // the rest, four walkers to a wavefront; everything else is one wide class.
         c->class_of.assign(n_regions, 0);
         const bool spectrum_like = c->packing == 0 && kmax <= PackSmall::KCAP && mean_p <= 128.0;
-        LaunchClass first, second;
-        first.kind = c->packing == 16 ? CK_SMALL : c->packing == 65 ? CK_MID : spectrum_like ? CK_SMALL : CK_WIDE;
-        second.kind = CK_MID;
+        LaunchClass cls[3];
+        cls[0].kind = c->packing == 16 ? CK_SMALL : c->packing == 65 ? CK_MID : spectrum_like ? CK_SMALL : CK_WIDE;
+        cls[1].kind = CK_MID;
+        cls[2].kind = CK_SMALL2;
         for (int r = 0; r < n_regions; ++r) {
-            const bool mid = spectrum_like && R[r].K >= 3 && R[r].P >= 96 && mode != VAMP_GAUSS3 && !c->f32;
-            (mid ? second : first).regions.push_back(r);
-            c->class_of[r] = mid ? 1 : 0;
+            int k = 0;
+            if (spectrum_like) {
+                if (R[r].K >= 3 && R[r].P >= 96 && mode != VAMP_GAUSS3 && !c->f32) k = 1;
+                else if (R[r].K <= PackSmall2::KCAP) k = 2;
+            }
+            cls[k].regions.push_back(r);
         }
-        if (first.regions.empty()) {
-            for (int r = 0; r < n_regions; ++r) c->class_of[r] = 0;
-            c->classes.push_back(second);
-        } else {
-            c->classes.push_back(first);
-            if (!second.regions.empty()) c->classes.push_back(second);
-        }
+        for (int k : {2, 0, 1})          // short single-line regions first, blends last
+            if (!cls[k].regions.empty()) {
+                for (int r : cls[k].regions) c->class_of[r] = (int)c->classes.size();
+                c->classes.push_back(cls[k]);
+            }
         if (c->classes.size() > 1)
             for (LaunchClass& cl : c->classes) {
                 HIP_TRY(hipMalloc(&cl.list_d, cl.regions.size() * sizeof(int)));
