@@ -454,6 +454,104 @@ def split_tables(seed, step, n_walkers, block, region=0):
     return red, blue
 
 
+# numpy-vectorised forms of the three functions above (same arithmetic on uint64 arrays), so that
+# production-size ensembles can be replayed in seconds; tests/test_oracle.py pins them to the scalar
+# forms.
+def _philox_vec(c0, c1, c2, c3, k0, k1):
+    c0, c1, c2, c3 = [np.asarray(v, dtype=np.uint64) & np.uint64(MASK32) for v in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = np.uint64(int(k0) & MASK32), np.uint64(int(k1) & MASK32)
+    m = np.uint64(MASK32)
+    s32 = np.uint64(32)
+    for _ in range(10):
+        p0 = np.uint64(PHILOX_M0) * c0
+        p1 = np.uint64(PHILOX_M1) * c2
+        c0, c1, c2, c3 = ((p1 >> s32) ^ c1 ^ k0) & m, p1 & m, ((p0 >> s32) ^ c3 ^ k1) & m, p0 & m
+        k0 = (k0 + np.uint64(PHILOX_W0)) & m
+        k1 = (k1 + np.uint64(PHILOX_W1)) & m
+    return c0, c1, c2, c3
+
+
+def _mulhi64(a, b):
+    """high 64 bits of the 128-bit product of uint64 arrays"""
+    m = np.uint64(MASK32)
+    s32 = np.uint64(32)
+    a0, a1, b0, b1 = a & m, a >> s32, b & m, b >> s32
+    t = a0 * b0
+    u = a1 * b0 + (t >> s32)
+    v = a0 * b1 + (u & m)
+    return a1 * b1 + (u >> s32) + (v >> s32)
+
+
+def split_perm_batch(seed, step, chunk, slot, block, region=0):
+    """split_perm for arrays of (chunk, slot)"""
+    chunk = np.asarray(chunk, dtype=np.uint64)
+    r0, r1, r2, r3 = _philox_vec(chunk, np.uint64(step & MASK32), np.uint64(STREAM_SPLIT), np.uint64(region & MASK32),
+                                 seed & MASK32, (seed >> 32) & MASK32)
+    bits = max(1, (block - 1).bit_length())
+    mask = np.uint64((1 << bits) - 1)
+    sh = np.uint64(max(1, bits // 2))
+    one = np.uint64(1)
+    x = np.broadcast_to(np.asarray(slot, dtype=np.uint64), r0.shape).copy()
+    done = np.zeros(x.shape, dtype=bool)
+    while not done.all():
+        y = (x * ((r0 << one) | one) + r1) & mask
+        y ^= y >> sh
+        y = (y * ((r2 << one) | one) + r3) & mask
+        y ^= y >> sh
+        y = (y * np.uint64(0x9E3779B1) + (r0 ^ r3)) & mask
+        y ^= y >> sh
+        x = np.where(done, x, y)
+        done |= x < np.uint64(block)
+    return x.astype(np.int64)
+
+
+def draw_move_batch(seed, step, half, walker_gid, n_complement, a=2.0):
+    """draw_move for an array of global walker ids: (z, partner_slot, log_u2) arrays"""
+    gid = np.asarray(walker_gid, dtype=np.uint64)
+    s32 = np.uint64(32)
+    k0, k1 = seed & MASK32, (seed >> 32) & MASK32
+    r = _philox_vec(gid, np.uint64(step & MASK32), np.uint64((half << 8) | STREAM_MOVE), gid >> s32, k0, k1)
+    u1 = (((r[0] << s32) | r[1]) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    t = (a - 1.0) * u1 + 1.0
+    z = t * t / a
+    j = _mulhi64((r[2] << s32) | r[3], np.uint64(n_complement)).astype(np.int64)
+    r2 = _philox_vec(gid, np.uint64(step & MASK32), np.uint64((half << 8) | STREAM_ACCEPT), gid >> s32, k0, k1)
+    u2 = (((r2[0] << s32) | r2[1]) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    with np.errstate(divide="ignore"):
+        logu = np.where(u2 > 0, np.log(u2), -np.inf)
+    return z, j, logu
+
+
+def split_tables_batch(seed, step, n_walkers, block, region=0):
+    """split_tables through split_perm_batch"""
+    half = block // 2
+    ch = np.repeat(np.arange(n_walkers // block), half)
+    s_ = np.tile(np.arange(half), n_walkers // block)
+    red = ch * block + split_perm_batch(seed, step, ch, s_, block, region)
+    blue = ch * block + split_perm_batch(seed, step, ch, s_ + half, block, region)
+    return red, blue
+
+
+def run_sampler_batch(lnprob_fn, X0, lnp0, n_steps, seed, block, a=2.0, step0=0, region=0, walker_off=0):
+    """run_sampler with the vectorised draws (same trajectory); returns chain, lnp_chain, n_accept"""
+    X = np.array(X0, dtype=np.float64)
+    lnp = np.array(lnp0, dtype=np.float64)
+    W = X.shape[0]
+    nacc = np.zeros(W, dtype=np.int64)
+    chain, lchain = [], []
+    for it in range(n_steps):
+        step = step0 + it
+        red, blue = split_tables_batch(seed, step, W, block, region)
+        for half in (0, 1):
+            act, comp = (red, blue) if half == 0 else (blue, red)
+            zz, j, logu = draw_move_batch(seed, step, half, act + walker_off, act.size, a)
+            acc, _ = stretch_half_step(X, lnp, act, comp[j], zz, logu, lnprob_fn)
+            nacc[act[acc]] += 1
+        chain.append(X.copy())
+        lchain.append(lnp.copy())
+    return np.array(chain), np.array(lchain), nacc
+
+
 # --------------------------------------------------------------------------------------
 # Stretch move (SURVEY Appendix B)
 # --------------------------------------------------------------------------------------

@@ -232,6 +232,50 @@ def test_mixed_launch_classes_match_oracle():
         assert np.allclose(chains[0][r], chains[16][r], rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_packed_launch_classes_at_production_size(dtype):
+    """Automatic packing only packs launches of >= 16 384 walkers, so the production shapes of a
+    spectrum-like context -- four walkers per wavefront with 2-line and 8-line LDS layouts, draws from
+    k_draws, and the 2-wavefront groups with Taylor tables -- run here at W = 32 768 on four q1422
+    regions (1, 2, 3 and >= 4 lines).  fp64: lnprob of every walker and two full stretch steps of
+    every walker against the oracle.  fp32: chi^2 within the stated 1e-3."""
+    import vamp_amd
+    from tools.bench_c3 import build_regions, start_walkers
+    xs, fs, ns, ks = build_regions()
+    pick = [next(r for r in range(len(xs)) if ks[r] == 1 and 30 <= len(xs[r]) <= 60)]
+    pick.append(next(r for r in range(len(xs)) if ks[r] >= 4 and 96 <= len(xs[r]) <= 200))
+    xs, fs, ns = [xs[r] for r in pick] * 2, [fs[r] for r in pick] * 2, [ns[r] for r in pick] * 2
+    ks = [1, ks[pick[1]], 2, 3]        # the same data with 2 and 3 lines: the 2-line layout and the short 8-line one
+    xs[3], fs[3], ns[3] = xs[3][:80], fs[3][:80], ns[3][:80]                # < 96 px: stays with the packed class
+    W = 32768
+    rng = np.random.default_rng(3)
+    th = [start_walkers(rng, x, k, W) for x, k in zip(xs, ks)]
+    regs = [vo.Region(x=x, flux=f, noise=n, n_comp=k, mode=vo.MODE_VOIGT4) for x, f, n, k in zip(xs, fs, ns, ks)]
+    with vamp_amd.HipContext(device=0, dtype=vamp_amd.F64 if dtype == "f64" else vamp_amd.F32) as ctx:
+        ctx.set_regions(xs, fs, ns, ks, mode=vamp_amd.MODE_VOIGT4)
+        la, ca = ctx.lnprob_all(th, return_chi2=True)
+        want = [vo.log_prob_batch_fast(reg, t) for reg, t in zip(regs, th)]
+        for r in range(4):
+            assert np.isfinite(want[r]).all()
+            if dtype == "f64":
+                assert np.max(np.abs(la[r] - want[r]) / np.maximum(1, np.abs(want[r]))) <= 1e-9, r
+            else:
+                assert np.max(np.abs(la[r] - want[r]) / np.abs(want[r])) <= 1e-3, r
+        if dtype == "f32":
+            return
+        ctx.sampler_init(th, seed=77, split_block=1024)
+        res = ctx.run(2)
+        for r, reg in enumerate(regs):
+            fn = lambda q, reg=reg: vo.log_prob_batch_fast(reg, q)
+            chain, lchain, nacc = vo.run_sampler_batch(fn, th[r], want[r], 2, seed=77, block=1024, region=r, walker_off=r * W)
+            # an accept decision whose margin is at rounding level (|log u - diff| ~ 1e-13 of 65 536
+            # decisions per region) may legitimately differ: allow a handful of walkers
+            ok = np.all(np.abs(res["chain"][r] - chain) <= 1e-10 * np.abs(chain) + 1e-12, axis=(0, 2))
+            assert (~ok).sum() <= 2, (r, int((~ok).sum()))
+            assert np.abs(res["n_accept"][r] - nacc).sum() <= 2, r
+            assert np.allclose(res["lnprob"][r][:, ok], lchain[:, ok], rtol=1e-9, atol=1e-9)
+
+
 def test_sampler_sd_mode_and_acceptance(hip_ctx):
     """Reference-form likelihood (free sd, vpfits.py:39): stored lnprob equals a fresh evaluation
     of the final positions, and the acceptance fraction is sane."""

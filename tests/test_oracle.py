@@ -239,6 +239,30 @@ def test_split_is_balanced_permutation():
     assert not np.array_equal(np.sort(red), np.sort(red2))
 
 
+def test_vectorised_draws_equal_the_scalar_restatement():
+    """draw_move_batch / split_perm_batch / run_sampler_batch (numpy on uint64 arrays, used to replay
+    production-size ensembles) against the scalar functions the golden trajectories were made with."""
+    seed = 0x1234ABCD5678EF01
+    gids = np.array([0, 1, 77, 65535, 2**32 + 5, 2**40 + 123], dtype=np.uint64)
+    for step, half, n in ((0, 0, 32768), (3, 1, 17), (2**31 + 9, 1, 2**20)):
+        z, j, lu = vo.draw_move_batch(seed, step, half, gids, n)
+        for i, g in enumerate(gids):
+            z1, j1, lu1 = vo.draw_move(seed, step, half, int(g), n)
+            assert z[i] == z1 and j[i] == j1 and lu[i] == lu1
+    for block in (8, 16, 100, 1024):
+        ch = np.repeat(np.arange(3), block)
+        sl = np.tile(np.arange(block), 3)
+        got = vo.split_perm_batch(seed, 5, ch, sl, block, region=2)
+        want = [vo.split_perm(seed, 5, int(c), int(s_), block, region=2) for c, s_ in zip(ch, sl)]
+        assert np.array_equal(got, want)
+    g = load_golden("stretch_traj.npz")
+    region = vo.Region(x=g["x"], flux=g["flux"], noise=g["noise"], n_comp=1, mode=vo.MODE_VOIGT4)
+    fn = lambda q: vo.log_prob_batch(region, q)
+    for blk in (8, 16):
+        chain, lchain, nacc = vo.run_sampler_batch(fn, g["X0"], g["lnp0"], 12, seed=seed, block=blk)
+        assert np.array_equal(chain, g[f"philox_chain_b{blk}"]) and np.array_equal(nacc, g[f"philox_nacc_b{blk}"])
+
+
 def test_stretch_golden_trajectories():
     g = load_golden("stretch_traj.npz")
     r = vo.Region(x=g["x"], flux=g["flux"], noise=g["noise"], n_comp=1, mode=vo.MODE_VOIGT4)

@@ -3,6 +3,7 @@
 
   python tools/variants.py build NAME=-DFLAG[,-DFLAG2] ...     (here; cross-compiles, no GPU)
   python tools/variants.py run [steps] [extra bench args...]    (on the GPU box; interleaved rounds)
+  python tools/variants.py runc3 [steps] [extra args...]         (the same on tools/bench_c3.py, config 3)
 """
 import json
 import os
@@ -27,6 +28,24 @@ if sys.argv[1] == "build":
     for name, p in procs:
         assert p.wait() == 0, name
     print("built", [n for n, _ in procs])
+elif sys.argv[1] == "runc3":
+    steps = sys.argv[2] if len(sys.argv) > 2 else "5"
+    extra = sys.argv[3:]
+    names = sorted(f[4:-3] for f in os.listdir(OUT) if f.startswith("lib_") and f.endswith(".so"))
+    res = {n: [] for n in names}
+    for rnd in range(2):
+        for n in names:
+            env = dict(os.environ, VAMP_HIP_LIB=os.path.join(OUT, f"lib_{n}.so"))
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_c3.py"), "--steps", steps] + extra,
+                                 env=env, capture_output=True, text=True)
+            try:
+                j = json.loads(out.stdout.strip().splitlines()[-1])
+                res[n].append(j["avg_launch_ms"])
+            except Exception as e:
+                print(n, "failed", e, out.stderr[-400:], flush=True)
+    for n in names:
+        if res[n]:
+            print(f"{n:24s} min {min(res[n]):8.3f} ms per half-step  all {['%.3f' % v for v in res[n]]}", flush=True)
 else:
     steps = sys.argv[2] if len(sys.argv) > 2 else "3"
     extra = sys.argv[3:]

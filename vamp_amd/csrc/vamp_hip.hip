@@ -118,7 +118,8 @@ struct Pack {
     static constexpr int WPB = WPB_;        // wavefronts per workgroup
     static constexpr int THREADS = 64 * WPB_;
     static constexpr int WALKERS_PER_BLOCK = SPLIT_ ? 1 : WPB_ * SUBS;
-    static_assert(!SPLIT_ || (LPW_ == 64 && WPB_ == PARTS), "a split workgroup is PARTS wavefronts on one walker");
+    static_assert(!SPLIT_ || (LPW_ == 64 && (WPB_ == PARTS || !FF_) && WPB_ <= PARTS),
+                  "a split workgroup is PARTS wavefronts on one walker (tile classes), or up to PARTS wavefronts without far field (contiguous shares)");
 };
 using PackWide = Pack<64, KMAX, true, WAVES_PER_BLOCK>;
 using PackWideFull = Pack<64, KMAX, false, WAVES_PER_BLOCK>;   // the headline shape: no tail code
@@ -129,11 +130,14 @@ using PackSmall = Pack<16, 8, true, 2>;
 // the same for regions of one or two lines (most regions of a real spectrum): 0.9 KB instead of
 // 3.7 KB of LDS per walker, so that registers, not LDS, set the occupancy
 using PackSmall2 = Pack<16, 2, true, 2>;
-// one walker per wavefront WITH its own Taylor tables (<= 8 lines: 18 KB + 3.7 KB of LDS per
-// single-wave workgroup, 7 per CU), no far field: the blended regions of real spectra (3..8 lines,
+// one walker per small workgroup WITH its own Taylor tables (<= 8 lines: 18 KB + 3.7 KB of LDS),
+// no far field; the group's wavefronts share the staging and take contiguous shares of the pixels: the blended regions of real spectra (3..8 lines,
 // ~100..500 px), where every pixel lies in some line's core and the near-axis rule (~190 issue
 // slots per evaluation against ~40 through a table) is the whole cost
-using PackMid = Pack<64, 8, true, 1, false, true, false>;
+#ifndef VAMP_MID_WAVES
+#define VAMP_MID_WAVES 2
+#endif
+using PackMid = Pack<64, 8, true, VAMP_MID_WAVES, true, true, false>;
 
 constexpr int FF_NODES = 16;          // Chebyshev nodes of the far-field interpolant of one tile
 #ifndef VAMP_FF_DIST
@@ -177,9 +181,12 @@ __device__ __forceinline__ double wave_sum(double v) {      // sum over the LPW 
     return v;
 }
 
-// literal restatement of vpfits.py:239-244: -inf for v<0, else log(v*exp(-v))
+// vpfits.py:239-244: -inf for v < 0, else log(v*exp(-v)).  For v <= 700 that is log(v) - v to an
+// ulp of the result (one transcendental instead of two); beyond, exp(-v) leaves the normal range
+// and the reference's literal form -- which ends in log(0) = -inf from v ~ 745 -- is kept.
 __device__ __forceinline__ double xexp_logp(double v) {
     if (!(v >= 0.0) || !isfinite(v)) return NEG_INF;
+    if (v <= 700.0) return log(v) - v;
     return log(v * exp(-v));
 }
 __device__ __forceinline__ double uniform_logp(double v, double lo, double hi, double lp) {
@@ -223,8 +230,9 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
         if constexpr (MODE == VAMP_GAUSS3) {
             rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0; rec.hy = 0.0; rec.xcap = __builtin_huge_val();
         } else {
-            rec.s = 2.0 * SQRT_LN2 / G;
-            rec.y = Lw * SQRT_LN2 / G;
+            const double rG = vamp::rcp_nr(G);          // one reciprocal for both scales (G = 0 -> inf -> rejected below)
+            rec.s = (2.0 * SQRT_LN2) * rG;
+            rec.y = (Lw * SQRT_LN2) * rG;
             rec.amp = a * rec.y;
             rec.pole = vamp::core_pole_factor(rec.y);
             rec.hy = vamp::core_hy(rec.y);
@@ -888,6 +896,23 @@ __device__ __forceinline__ double sweep_pixels(const RegionDev& R, const WalkerL
         double chi = 0.0;
         sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, 0, full, TILE, true, chi, tab);
         return wave_sum<PK::LPW>(chi);
+    } else if constexpr (PK::SPLIT && !PK::FF) {
+        // a blend of a few hundred pixels: the group's wavefronts take contiguous shares of the region
+        // (whole 16-pixel runs), each swept as full tiles + one iteration of 1..4 pixels per lane
+        const int share = ((R.P + PK::WPB - 1) / PK::WPB + 15) & ~15;
+        const int lo = part * share;
+        RegionDev Rs = R;
+        Rs.P = lo + share < R.P ? lo + share : R.P;           // this wave's pixels end here
+        double chi = 0.0;
+        if (lo < Rs.P)
+            sweep_class<F32, MODE, PK>(Rs, L, Sx, dct, px, lane, lo, lo + ((Rs.P - lo) / TILE) * TILE, TILE, true, chi, tab);
+        chi = wave_sum<64>(chi);
+        if (lane == 0) red[part] = chi;
+        __syncthreads();
+        double total = 0.0;
+#pragma unroll
+        for (int p = 0; p < PK::WPB; ++p) total += red[p];
+        return total;
     } else if constexpr (PK::SPLIT) {
         double chi = 0.0;
         sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, part * TILE, full, PARTS * TILE, part == 0, chi, tab);

@@ -147,14 +147,18 @@ VAMP_DEV double cos_small(double a) {
 // Per-line constants of the near-axis rule, computed once per (walker, component).
 // Table entry i <-> node n = i - DTAB_OFF, u_n = (n + 1/2) h; d is even in u, so negative n need
 // no special casing and a pixel reads dtab[n0 + DTAB_OFF +- j] with compile-time offsets.
+// (reciprocals through rcp_nr -- v_rcp_f64 + two Newton steps, within an ulp -- and exponentials
+// through exp_taylor: an IEEE fp64 divide is ~35 instructions on gfx950, and these run once per
+// (walker, line, node), which is most of the work of a 40-pixel region)
 VAMP_DEV double core_dtab_entry(int i, double y) {
     double u = ((i - DTAB_OFF) + 0.5) * CORE_H;
-    return 1.0 / (u * u + y * y);
+    return rcp_nr(fma(u, u, y * y));
 }
 VAMP_DEV double core_pole_factor(double y) {      // sqrt(pi) * A(y)
-    if (!(y < Y_POLE_MAX)) return 0.0;
-    double t = exp(-2.0 * PI * y / CORE_H);
-    return SQRT_PI * 2.0 * exp(y * y - 2.0 * PI * y / CORE_H) / (1.0 + t);
+    if (!(y < Y_POLE_MAX)) return 0.0;            // (NaN: no pole term)
+    const double a = (-2.0 * PI / CORE_H) * y;    // <= 0
+    const double t = exp_taylor(a);
+    return (SQRT_PI * 2.0) * exp_taylor(fma(y, y, a)) * rcp_nr(1.0 + t);     // y^2 - 4 pi y < 0 for y < 4.5
 }
 VAMP_DEV double core_hy(double y) { return (CORE_H * INV_SQRT_PI) * y; }
 
