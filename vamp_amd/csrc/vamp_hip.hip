@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,6 +42,9 @@
 
 #ifndef VAMP_EARLY_LOADS
 #define VAMP_EARLY_LOADS 1
+#endif
+#ifndef VAMP_SR_EARLY
+#define VAMP_SR_EARLY 0
 #endif
 namespace {
 
@@ -135,7 +139,10 @@ using PackSmall2 = Pack<16, 2, true, 2>;
 // ~100..500 px), where every pixel lies in some line's core and the near-axis rule (~190 issue
 // slots per evaluation against ~40 through a table) is the whole cost
 #ifndef VAMP_MID_WAVES
-#define VAMP_MID_WAVES 2
+#define VAMP_MID_WAVES 1
+#endif
+#ifndef VAMP_MID_PREDRAW
+#define VAMP_MID_PREDRAW 1
 #endif
 using PackMid = Pack<64, 8, true, VAMP_MID_WAVES, true, true, false>;
 
@@ -255,7 +262,11 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
     }
     lp = wave_sum<PK::LPW>(lp);
     group_barrier<PK>();
+#ifdef VAMP_SKIP_DTAB     // timing-only builds (tools/variants.py)
+    if (false) {
+#else
     if (MODE != VAMP_GAUSS3 && !want_f32) {
+#endif
         constexpr int STEP = PK::SPLIT ? PK::THREADS : PK::LPW;
         for (int e = PK::SPLIT ? 64 * part + lane : lane; e < K * vamp::DTAB_N; e += STEP) {
             const int k = e / vamp::DTAB_N, n = e % vamp::DTAB_N;
@@ -263,7 +274,11 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
         }
     }
     group_barrier<PK>();
+#ifdef VAMP_SKIP_TAB      // timing-only builds (tools/variants.py)
+    if constexpr (false) {
+#else
     if constexpr (TAB) {
+#endif
         // one (line, interval) pair per thread: 16 lines x 16 intervals = the 256 threads of a split
         // group; a single wavefront takes its walker's pairs 64 at a time
         constexpr int TSTEP = PK::SPLIT ? PK::THREADS : PK::LPW;
@@ -415,6 +430,17 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<
             xi[t] = x[idx[t]];
             tau[t] = 0.0;
         }
+#if VAMP_SR_EARLY
+        // flux and weights requested now, used after the evaluations: their L2 round trip overlaps the
+        // arithmetic instead of following it (the compiler sinks loads to their use)
+        double fi[T], wi[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            fi[t] = f[idx[t]];
+            wi[t] = wt[idx[t]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if constexpr (gauss) {
             for (int k = 0; k < K; ++k) {
                 const double c = L.line[k].c, s = L.line[k].s, a = L.line[k].amp;
@@ -438,7 +464,11 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const double m = vamp::exp_taylor(-tau[t]);
+#if VAMP_SR_EARLY
+            const double r = (fi[t] - m) * wi[t];
+#else
             const double r = (f[idx[t]] - m) * wt[idx[t]];
+#endif
             const bool live = (base + LPW * t + lane) < P;
             chi += live ? r * r : 0.0;
         }
@@ -956,7 +986,11 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::
         if (chi_out) *chi_out = __builtin_nan("");
         return NEG_INF;
     }
+#ifdef VAMP_SKIP_SWEEP    // timing-only builds (tools/variants.py)
+    const double ssum = L.line[0].y + L.dtab[0][lane & 31] + (tab ? tab[lane] : 0.0);
+#else
     const double ssum = sweep_pixels<F32, MODE, PK>(R, L, Sx, dct, px, lane, part, red, tab);
+#endif
     if (chi_out) *chi_out = ssum;
     double v = lp + loglike_from_sum(R, L, ssum);
     if (v != v) v = NEG_INF;                 // NaN -> -inf (emcee convention)
@@ -1238,17 +1272,21 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
     WalkerLds<PK::KCAP>& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
     double* Xs = S.X + R.theta_off + ws * R.D;
     const double* Xc = S.X + R.theta_off + wc * R.D;
+    const long long wg = R.walker_off + ws;
+    // the mover's current lnprob is requested together with the two rows: three random reads of a
+    // state far larger than L2, one exposed round trip instead of two (it is needed only for the
+    // accept test, and left there its miss is paid in full by the one or two waves a SIMD holds)
+    double lnp_s = S.lnp[wg];
     if (!PK::SPLIT || wave == 0)
         for (int d = l; d < R.D; d += PK::LPW) {
             const double c = Xc[d];
             L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
         }
+    asm volatile("" : "+v"(lnp_s));                          // keep the read up here
     group_barrier<PK>();
     const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, scr[PK::FF ? wave : 0], dct, px, l, nullptr, wave, red,
                                                     tabs[PK::SPLIT ? 0 : wave].a);
     if (PK::SPLIT && wave != 0) return;     // the group's first wave carries out the accept step
-    const long long wg = R.walker_off + ws;
-    const double lnp_s = S.lnp[wg];
     if constexpr (DRAWS != DRAW_PRE) logz = log(z);
     const double diff = (double)(R.D - 1) * logz + lnp_q - lnp_s;
     const bool accept = logu < diff;                      // false for NaN
@@ -1374,6 +1412,13 @@ struct vamp_ctx {
     int *dr_ws = nullptr, *dr_wc = nullptr;
     double *dr_z = nullptr, *dr_lu = nullptr, *dr_lz = nullptr;
     long long dr_cap = 0;
+    // launch classes of one half-step run concurrently, each on its own stream (forked from and joined
+    // to the ctx stream with events): a class of low-occupancy blends and a class of register-bound
+    // short regions fill each other's stalls
+    bool concurrent_classes = true;
+    std::vector<hipStream_t> cls_stream;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
     std::vector<RegionDev> regions_h;
     RegionDev* regions_d = nullptr;
     long long n_pix = 0;
@@ -1539,7 +1584,26 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     // <16 lanes, 8 lines> packing needs every wave inside one region and one shard
     const int subs = PackSmall::SUBS;
     const bool packable = !ext && halfW % subs == 0 && (c->split_block / 2) % subs == 0;
-    for (size_t ci = 0; ci < c->classes.size(); ++ci) {
+    const size_t ncls = c->classes.size();
+    const bool fork = !ext && ncls > 1 && c->concurrent_classes;
+    if (fork) {
+        while (c->cls_stream.size() < ncls - 1) {
+            hipStream_t st;
+            hipEvent_t ev;
+            HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->cls_stream.push_back(st);
+            c->ev_join.push_back(ev);
+        }
+        if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    }
+    // draws of the packed classes: one slice of the buffers per class (the classes may overlap in time)
+    long long draw_total = 0;
+    if (!ext)
+        for (const LaunchClass& cl : c->classes) draw_total += (c->n_regions == 1) ? c->total_walkers : (long long)cl.regions.size() * halfW;
+    long long draw_off = 0;
+    for (size_t ci = 0; ci < ncls; ++ci) {
         const LaunchClass& cl = c->classes[ci];
         if (ext && c->class_of[ext_region] != (int)ci) continue;
         long long n;
@@ -1555,39 +1619,52 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
             n = S.slot_end;
         }
         if (n <= 0) continue;
+        hipStream_t st = c->stream;
+        if (fork && ci > 0) {
+            st = c->cls_stream[ci - 1];
+            HIP_TRY(hipStreamWaitEvent(st, c->ev_fork, 0));
+        }
         S.region_list = cl.list_d;
         const int shape = class_shape(c, cl, n, packable);
         const unsigned grid = (unsigned)((n + shape_walkers_per_block(shape) - 1) / shape_walkers_per_block(shape));
         const dim3 threads(shape_threads(shape));
         if (ext) {
             if (c->f32)
-                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<true, DRAW_HOST, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<true, DRAW_HOST, M, PK>), dim3(grid), threads, 0, st, S, px, step,
                                                           half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d, nd));
             else
-                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_HOST, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_HOST, M, PK>), dim3(grid), threads, 0, st, S, px, step,
                                                           half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d, nd));
-        } else if (shape == SH_SMALL || shape == SH_SMALL2) {
-            // four walkers per wavefront: draws in their own one-thread-per-mover launch
-            int rc = ensure_draw_buffers(c, n);
+        } else if (shape == SH_SMALL || shape == SH_SMALL2 || (shape == SH_MID && VAMP_MID_PREDRAW)) {
+            // four walkers per wavefront (or a walker per wavefront at ~1.7 wavefronts per SIMD, where
+            // ~1000 scalar instructions of draws are exposed latency): draws in their own
+            // one-thread-per-mover launch
+            int rc = ensure_draw_buffers(c, draw_total);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_draws, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, S, step, half, n, c->dr_ws,
-                               c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz);
+            int *d_ws = c->dr_ws + draw_off, *d_wc = c->dr_wc + draw_off;
+            double *d_z = c->dr_z + draw_off, *d_lu = c->dr_lu + draw_off, *d_lz = c->dr_lz + draw_off;
+            draw_off += n;
+            hipLaunchKernelGGL(k_draws, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, step, half, n, d_ws, d_wc, d_z, d_lu, d_lz);
             HIP_TRY(hipGetLastError());
             if (c->f32)
-                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<true, DRAW_PRE, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
-                                                          half, 0, 0ll, c->dr_ws, c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz));
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<true, DRAW_PRE, M, PK>), dim3(grid), threads, 0, st, S, px, step,
+                                                          half, 0, 0ll, d_ws, d_wc, d_z, d_lu, d_lz));
             else
-                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_PRE, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
-                                                          half, 0, 0ll, c->dr_ws, c->dr_wc, c->dr_z, c->dr_lu, c->dr_lz));
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_PRE, M, PK>), dim3(grid), threads, 0, st, S, px, step,
+                                                          half, 0, 0ll, d_ws, d_wc, d_z, d_lu, d_lz));
         } else {
             if (c->f32)
-                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<true, DRAW_INLINE, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<true, DRAW_INLINE, M, PK>), dim3(grid), threads, 0, st, S, px, step,
                                                           half, 0, 0ll, ni, ni, nd, nd, nd));
             else
-                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_INLINE, M, PK>), dim3(grid), threads, 0, c->stream, S, px, step,
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_INLINE, M, PK>), dim3(grid), threads, 0, st, S, px, step,
                                                           half, 0, 0ll, ni, ni, nd, nd, nd));
         }
         HIP_TRY(hipGetLastError());
+        if (fork && ci > 0) {
+            HIP_TRY(hipEventRecord(c->ev_join[ci - 1], st));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join[ci - 1], 0));
+        }
     }
     if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
     return 0;
@@ -1749,6 +1826,7 @@ int vamp_ctx_create(vamp_ctx** out, int device, int dtype, int wofz_kind) {
         return fail(VAMP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    if (const char* e = getenv("VAMP_CLASS_STREAMS")) c->concurrent_classes = std::atoi(e) != 0;
     *out = c;
     return VAMP_OK;
 }
@@ -1762,8 +1840,12 @@ int vamp_ctx_destroy(vamp_ctx* c) {
     free_sampler(c);
     free_regions(c);
     for (void* p : {(void*)c->ext_act_d, (void*)c->ext_par_d, (void*)c->ext_z_d, (void*)c->ext_lu_d, (void*)c->sc_th,
-                    (void*)c->sc_lp, (void*)c->sc_chi})
+                    (void*)c->sc_lp, (void*)c->sc_chi, (void*)c->dr_ws, (void*)c->dr_wc, (void*)c->dr_z, (void*)c->dr_lu,
+                    (void*)c->dr_lz})
         if (p) (void)hipFree(p);
+    for (hipStream_t st : c->cls_stream) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : c->ev_join) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (auto& p : c->ev) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);

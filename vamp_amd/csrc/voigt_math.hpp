@@ -374,27 +374,45 @@ VAMP_DEV void sincos_small(double a, double& sn_out, double& cs_out) {
 // d = 0, real part as in voigt_core, imaginary part from the same nodes:
 //     sqrt(pi) Im w = (h / sqrt(pi)) sum_n e^{-(x - u_n)^2} u_n / (u_n^2 + y^2) - sqrt(pi) A(y) e^{-x^2} sin(2 x y)
 VAMP_DEV void core_centre(int i, double y, const double* dtab, double pole, double hy, double& re, double& im) {
+    // weights c_j = e^{-j^2/4}; with u_{i+-j} = x_i +- j h the imaginary sum splits into the real one
+    // and an antisymmetric one:  sum_j c_j u_{i+j} p_{i+j} = x_i S0 + h S1,
+    //   S0 = p_0 + sum_{j>0} c_j (p_j + p_-j),   S1 = sum_{j>0} j c_j (p_j - p_-j)
+    // -- two multiply-adds per node pair, no per-node abscissae
     constexpr double CJ[CORE_J + 1] = {1.0, 0.77880078307140486825, 0.3678794411714423216, 0.10539922456186433678,
                                        0.018315638888734180294, 0.0019304541362277092422, 0.0001234098040866795495,
                                        4.7851173921290090896e-6, 1.1253517471925911451e-7, 1.6052280551856116087e-9,
                                        1.3887943864964020595e-11, 7.2877240958196924193e-14, 2.3195228302435693883e-16,
                                        4.477732441718301199e-19};
+    constexpr double JCJ[CORE_J + 1] = {0.0, 7.78800783071404878e-01, 7.35758882342884668e-01, 3.16197673685592984e-01,
+                                        7.32625555549367147e-02, 9.65227068113854586e-03, 7.40458824520077367e-04,
+                                        3.34958217449030638e-05, 9.00281397754072932e-07, 1.44470524966705042e-08,
+                                        1.38879438649640215e-10, 8.01649650540166128e-13, 2.78342739629228356e-15,
+                                        5.82105217423379233e-18};
     const double* p = dtab + i + DTAB_OFF;
-    double sre = 0.0, sim = 0.0;
+    // all 27 table reads first, arithmetic after: scheduled one by one next to their use (the
+    // compiler's choice) each read is an exposed LDS round trip for the one or two wavefronts a SIMD
+    // holds while tables are built
+    double pv[2 * CORE_J + 1];
+#pragma unroll
+    for (int j = 0; j <= 2 * CORE_J; ++j) pv[j] = p[j - CORE_J];
+#if defined(__HIPCC__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
     for (int j = CORE_J; j >= 1; --j) {          // small terms first
-        const double a = CJ[j] * p[j], b = CJ[j] * p[-j];
-        sre += a + b;
-        sim = fma(a, ((i + j) + 0.5) * CORE_H, fma(b, ((i - j) + 0.5) * CORE_H, sim));
+        const double a = pv[CORE_J + j], b = pv[CORE_J - j];
+        s0 = fma(CJ[j], a + b, s0);
+        s1 = fma(JCJ[j], a - b, s1);
     }
-    sre += p[0];
-    sim = fma(p[0], (i + 0.5) * CORE_H, sim);
+    s0 += pv[CORE_J];
     const double x = (i + 0.5) * CORE_H;
-    re = hy * sre;
-    im = (CORE_H * INV_SQRT_PI) * sim;
+    re = hy * s0;
+    im = (CORE_H * INV_SQRT_PI) * fma(x, s0, CORE_H * s1);
     if (pole != 0.0) {
         double sn, cs;
         sincos_small(2.0 * x * y, sn, cs);
-        const double e = pole * exp_neg_sq(x);
+        const double e = pole * exp_taylor(-(x * x));      // x = (2 i + 1)/4: x^2 is exact
         re = fma(e, cs, re);
         im = fma(-e, sn, im);
     }
@@ -403,21 +421,42 @@ VAMP_DEV void core_centre(int i, double y, const double* dtab, double pole, doub
 // the TAB_NT coefficients of interval i, written to out[0 .. TAB_NT)
 VAMP_DEV void taylor_table_row(int i, double y, const double* dtab, double pole, double hy, double* out) {
     double c0r, c0i;
+#ifdef VAMP_TT_NOCENTRE     // timing-only builds (tools/variants.py)
+    c0r = hy + dtab[i]; c0i = pole;
+#else
     core_centre(i, y, dtab, pole, hy, c0r, c0i);
+#endif
     const double zr = (i + 0.5) * CORE_H, zi = y;
     // c_1 = -2 z c_0 + 2i
     double c1r = -2.0 * (zr * c0r - zi * c0i);
     double c1i = fma(-2.0, fma(zr, c0i, zi * c0r), 2.0);
     out[0] = c0r;
     out[1] = c1r;
+    // (unrolled, so that -2/(n+1) is a literal: left as a loop this was a 35-instruction fp64 divide per
+    // coefficient -- more than the rest of the table row together)
+#ifdef VAMP_TT_NOREC         // timing-only builds (tools/variants.py)
+    for (int n = 1; n + 1 < TAB_NT; ++n) out[n + 1] = c1i;
+    return;
+#endif
+#ifdef VAMP_TT_NOSTORE       // timing-only builds: all the arithmetic, one store per row
+    double acc = 0.0;
+#endif
+#pragma unroll
     for (int n = 1; n + 1 < TAB_NT; ++n) {
         const double f = -2.0 / (double)(n + 1);
         const double nr = f * (fma(zr, c1r, -zi * c1i) + c0r);
         const double ni = f * (fma(zr, c1i, zi * c1r) + c0i);
         c0r = c1r; c0i = c1i;
         c1r = nr; c1i = ni;
+#ifdef VAMP_TT_NOSTORE
+        acc += nr;
+#else
         out[n + 1] = nr;
+#endif
     }
+#ifdef VAMP_TT_NOSTORE
+    out[2] = acc;
+#endif
 }
 
 // sqrt(pi) H(x, y) for 0 <= x < 8 from the line's table
