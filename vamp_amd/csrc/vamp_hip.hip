@@ -43,6 +43,9 @@
 #ifndef VAMP_EARLY_LOADS
 #define VAMP_EARLY_LOADS 1
 #endif
+#ifndef VAMP_EARLY_LNP
+#define VAMP_EARLY_LNP 1
+#endif
 #ifndef VAMP_SR_EARLY
 #define VAMP_SR_EARLY 0
 #endif
@@ -133,7 +136,10 @@ using PackSplitFull = Pack<64, KMAX, false, PARTS, true>;
 using PackSmall = Pack<16, 8, true, 2>;
 // the same for regions of one or two lines (most regions of a real spectrum): 0.9 KB instead of
 // 3.7 KB of LDS per walker, so that registers, not LDS, set the occupancy
-using PackSmall2 = Pack<16, 2, true, 2>;
+#ifndef VAMP_SMALL2_WAVES
+#define VAMP_SMALL2_WAVES 2
+#endif
+using PackSmall2 = Pack<16, 2, true, VAMP_SMALL2_WAVES>;
 // one walker per small workgroup WITH its own Taylor tables (<= 8 lines: 18 KB + 3.7 KB of LDS),
 // no far field; the group's wavefronts share the staging and take contiguous shares of the pixels: the blended regions of real spectra (3..8 lines,
 // ~100..500 px), where every pixel lies in some line's core and the near-axis rule (~190 issue
@@ -1282,7 +1288,9 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
             const double c = Xc[d];
             L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
         }
+#if VAMP_EARLY_LNP
     asm volatile("" : "+v"(lnp_s));                          // keep the read up here
+#endif
     group_barrier<PK>();
     const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, scr[PK::FF ? wave : 0], dct, px, l, nullptr, wave, red,
                                                     tabs[PK::SPLIT ? 0 : wave].a);
@@ -1373,11 +1381,11 @@ enum Shape { SH_SMALL = 0, SH_MID = 1, SH_WIDE = 2, SH_WIDE_FULL = 3, SH_SPLIT =
         else { using PK = PackWide; VAMP_FOR_MODE_(mode, __VA_ARGS__); }        \
     } while (0)
 inline long long shape_walkers_per_block(int sh) {
-    return (sh == SH_SMALL || sh == SH_SMALL2) ? PackSmall::WALKERS_PER_BLOCK : sh == SH_MID ? PackMid::WALKERS_PER_BLOCK
+    return sh == SH_SMALL ? PackSmall::WALKERS_PER_BLOCK : sh == SH_SMALL2 ? PackSmall2::WALKERS_PER_BLOCK : sh == SH_MID ? PackMid::WALKERS_PER_BLOCK
            : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? 1 : PackWide::WALKERS_PER_BLOCK;
 }
 inline unsigned shape_threads(int sh) {
-    return (sh == SH_SMALL || sh == SH_SMALL2) ? PackSmall::THREADS : sh == SH_MID ? PackMid::THREADS
+    return sh == SH_SMALL ? PackSmall::THREADS : sh == SH_SMALL2 ? PackSmall2::THREADS : sh == SH_MID ? PackMid::THREADS
            : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? PackSplit::THREADS : PackWide::THREADS;
 }
 
@@ -2007,7 +2015,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
             }
             cls[k].regions.push_back(r);
         }
-        for (int k : {2, 0, 1})          // short single-line regions first, blends last
+        for (int k : {1, 2, 0})          // blends first: the longest launch starts first when the classes overlap
             if (!cls[k].regions.empty()) {
                 for (int r : cls[k].regions) c->class_of[r] = (int)c->classes.size();
                 c->classes.push_back(cls[k]);

@@ -36,6 +36,10 @@
 #define VAMP_DEV static inline   // host build of the same arithmetic, used by tests/ only
 #endif
 
+#ifndef VAMP_CC_FRONTLOAD
+#define VAMP_CC_FRONTLOAD 1
+#endif
+
 namespace vamp {
 
 constexpr double INV_SQRT_PI = 0.56418958354775628695;
@@ -395,7 +399,7 @@ VAMP_DEV void core_centre(int i, double y, const double* dtab, double pole, doub
     double pv[2 * CORE_J + 1];
 #pragma unroll
     for (int j = 0; j <= 2 * CORE_J; ++j) pv[j] = p[j - CORE_J];
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && VAMP_CC_FRONTLOAD
     __builtin_amdgcn_sched_barrier(0);
 #endif
     double s0 = 0.0, s1 = 0.0;
