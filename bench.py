@@ -194,10 +194,41 @@ def cpu_c_port(wl, budget_s=10.0):
             "sample": f"first {Wc} walkers of the same workload x 1 step on {cores} threads, {t:.1f} s"}
 
 
+def cpu_host_abi(wl, budget_s=8.0):
+    """Third figure (BASELINE.md Baseline B): oracle/libvamp_cpu.so, the C ABI of include/vamp_hip.h
+    implemented on the host (OpenMP over walkers, the host build of the product's Voigt evaluators,
+    the same sampler), driven through the same ctypes wrapper as the GPU library."""
+    so = os.path.join(ROOT, "oracle", "libvamp_cpu.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    from vamp_amd import _lib, hip_backend
+    ctx = hip_backend.HipContext(lib=_lib.bind(so))
+    ctx.set_regions(wl["x"], wl["flux"], wl["noise"], wl["K"], mode=wl["mode"], nbz=wl["nbz"])
+    cores = len(os.sched_getaffinity(0))
+
+    def run(Wc):
+        blk = hip_backend.default_split_block(Wc)
+        ctx.sampler_init(np.ascontiguousarray(wl["theta0"][:Wc]), seed=7, split_block=blk)
+        return ctx.run(1, store_chain=False)["seconds"]
+
+    Wc = min(wl["W"], 4 * cores)
+    t = run(Wc)
+    while t < budget_s / 4 and Wc < wl["W"]:
+        Wc = int(min(wl["W"], Wc * min(8.0, max(2.0, 0.7 * budget_s / t))))
+        Wc -= Wc % 2
+        t = run(Wc)
+    ctx.close()
+    return {"value": Wc / t, "unit": "walker-steps/s", "cores": cores, "kind": "port",
+            "path": "oracle/libvamp_cpu.so: the C ABI of include/vamp_hip.h on the host (OpenMP, host build of voigt_math.hpp)",
+            "sample": f"first {Wc} walkers of the same workload x 1 step on {cores} threads, {t:.1f} s"}
+
+
 def cpu_baseline(wl):
-    """`value` is the path BASELINE.json names; the C port is reported beside it."""
+    """`value` is the path BASELINE.json names; the two compiled ports are reported beside it."""
     out = cpu_reference_path(wl)
     out["c_port"] = cpu_c_port(wl)
+    out["host_abi"] = cpu_host_abi(wl)
     return out
 
 

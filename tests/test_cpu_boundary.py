@@ -1,0 +1,166 @@
+"""CPU tests (-m "not gpu") of the drop-in boundary through the HOST implementation of the C ABI
+(oracle/libvamp_cpu.so: the same header, include/vamp_hip.h, implemented with OpenMP and the host
+build of the Voigt evaluators).  Test infrastructure: the library is bound explicitly here
+(``_lib.bind``); vamp_amd itself never loads it.
+
+What this buys without a GPU: the ctypes layer, argument checks and error codes, the call-order
+rules, the MAP search, the sampler's draws / sharding / pack-and-scatter arithmetic and the VPfit
+facade all run for real, against the same oracle and golden vectors as the GPU parity tests -- the
+parity tests of tests/test_gpu_parity.py are reused verbatim with this context."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import vamp_oracle as vo
+
+import test_gpu_parity as gp
+import test_gpu_vpfit as gv
+
+CPU_SO = os.path.join(ROOT, "oracle", "libvamp_cpu.so")
+
+
+@pytest.fixture(scope="module")
+def cpu_lib():
+    if not os.path.exists(CPU_SO):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    from vamp_amd import _lib
+    return _lib.bind(CPU_SO)
+
+
+@pytest.fixture
+def cpu_ctx(cpu_lib):
+    import vamp_amd
+    ctx = vamp_amd.HipContext(lib=cpu_lib)
+    ctx.packing_request = 64
+    yield ctx
+    ctx.close()
+
+
+def test_host_library_exports_the_whole_header(cpu_lib):
+    import subprocess
+    from test_abi import _header_functions
+    out = subprocess.check_output(["nm", "-D", "--defined-only", CPU_SO], text=True)
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T vamp_" in l)
+    assert exported == _header_functions()
+    assert cpu_lib.vamp_version() == 2
+
+
+@pytest.mark.parametrize("fn", [gp.test_device_wofz_matches_scipy_and_mpmath, gp.test_lnprob_matches_golden,
+                                gp.test_line_records_and_prior_match_oracle, gp.test_lnprob_include_norm_and_bounds,
+                                gp.test_multi_region_batch_matches_single, gp.test_stretch_injected_draws_parity,
+                                gp.test_sampler_resume_and_thin, gp.test_sampler_multi_region_matches_oracle,
+                                gp.test_sampler_sd_mode_and_acceptance, gp.test_map_all_follows_scipy_fmin],
+                         ids=lambda f: f.__name__)
+def test_gpu_parity_test_through_the_host_abi(fn, cpu_ctx):
+    fn(cpu_ctx)
+
+
+@pytest.mark.parametrize("block", [8, 16])
+def test_philox_trajectory_through_the_host_abi(cpu_ctx, block):
+    gp.test_stretch_philox_trajectory_parity(cpu_ctx, block)
+
+
+def test_error_codes_and_call_order(cpu_lib, cpu_ctx):
+    import vamp_amd
+    E = vamp_amd._lib.VampError
+    g = load_golden("stretch_traj.npz")
+    z4, out1 = np.zeros(4), np.zeros(1)
+    dp = lambda a: a.ctypes.data_as(vamp_amd._lib.c_double_p)
+    assert cpu_lib.vamp_lnprob(cpu_ctx._h, 0, 1, dp(z4), dp(out1), None) == -5          # before set_regions
+    assert b"vamp_set_regions first" in cpu_lib.vamp_last_error()
+    with pytest.raises(E) as e:
+        vamp_amd.HipContext(dtype=vamp_amd.F32, wofz_kind=0, lib=cpu_lib)
+    assert e.value.code == -1
+    for bad in (np.r_[g["x"][:5], g["x"][3], g["x"][6:]], np.r_[g["x"][:4], np.nan, g["x"][5:]]):
+        with pytest.raises(E) as e:
+            cpu_ctx.set_regions(bad, g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)
+        assert e.value.code == -1
+    cpu_ctx.set_regions(g["x"], g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)
+    with pytest.raises(E) as e:
+        cpu_ctx.half_step(0)                                  # before sampler_init
+    assert e.value.code == -5
+    with pytest.raises(E) as e:
+        cpu_ctx.sampler_init(g["X0"][:15], seed=1, split_block=5)
+    assert e.value.code == -1
+    cpu_ctx.sampler_init(g["X0"], seed=1, split_block=8)
+    with pytest.raises(E):                                    # partner inside the active set
+        cpu_ctx.half_step_ext([0, 1], [1, 2], [1.0, 1.0], [0.0, 0.0])
+    with pytest.raises(E) as e:                               # W/split_block = 2 chunks cannot feed 4 ranks
+        cpu_ctx.sampler_set_shard_parts(0, 4, 1)
+    assert e.value.code == -1
+    cpu_ctx.sampler_set_shard_parts(1, 2, 1)
+    with pytest.raises(E) as e:                               # a shard without a communicator is stepped by the host
+        cpu_ctx.run(1)
+    assert e.value.code == -5
+    th = g["X0"].copy()
+    th[0, 0] = np.nan
+    th[1, 3] = np.inf
+    out = cpu_ctx.lnprob(th)
+    assert out[0] == -np.inf and out[1] == -np.inf and np.isfinite(out[2:]).all()
+
+
+def test_pack_and_scatter_arithmetic(cpu_ctx):
+    """The active-colour exchange of a 2-shard context (vamp_sampler_pack_get / scatter_put): same
+    assertions as the GPU test of the scatter kernel."""
+    g = load_golden("stretch_traj.npz")
+    region = vo.Region(x=g["x"], flux=g["flux"], noise=g["noise"], n_comp=1, mode=vo.MODE_VOIGT4)
+    rng = np.random.default_rng(18)
+    X0 = np.stack([rng.uniform(0.3, 1.5, 64), rng.uniform(-4, 4, 64), rng.uniform(0.5, 3, 64), rng.uniform(2, 8, 64)], 1)
+    cpu_ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vo.MODE_VOIGT4)
+    cpu_ctx.sampler_init(X0, seed=5, split_block=16)
+    (b, e), = cpu_ctx.sampler_set_shard_parts(1, 2, 1)
+    assert (b, e) == (32, 64)
+    cpu_ctx.half_step_part(0, 0)
+    mine = cpu_ctx.pack_get(0)
+    X1, lnp1, _, _ = cpu_ctx.get_state()
+    red, blue = vo.split_tables(5, 0, 64, 16)
+    assert np.array_equal(mine[:, :-1], X1[red[16:]]) and np.array_equal(mine[:, -1], lnp1[red[16:]])
+    foreign = np.arange(16 * 5, dtype=np.float64).reshape(16, 5) + 1000.0
+    cpu_ctx.scatter_put(0, np.concatenate([foreign, -mine]))
+    X2, lnp2, _, _ = cpu_ctx.get_state()
+    assert np.array_equal(X2[red[:16]], foreign[:, :-1]) and np.array_equal(lnp2[red[:16]], foreign[:, -1])
+    keep = np.ones(64, dtype=bool)
+    keep[red[:16]] = False
+    assert np.array_equal(X2[keep], X1[keep]) and np.array_equal(lnp2[keep], lnp1[keep])
+
+
+def test_single_rank_exchange_rehearsal(cpu_ctx):
+    """comm of one rank + pieces: the call sequence of the production multi-GPU path, same chain"""
+    from vamp_amd.ensemble import ShardedEnsemble
+    g = load_golden("stretch_traj.npz")
+    cpu_ctx.set_regions(g["x"], g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)
+    cpu_ctx.sampler_init(g["X0"], seed=99, split_block=4)
+    ref = cpu_ctx.run(5)
+    import vamp_amd
+    with vamp_amd.HipContext(lib=cpu_ctx._lib) as ctx:
+        ctx.set_regions(g["x"], g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)
+        # comm id comes from the bound library: patch the module-level helper for this context
+        ctx.comm_init_rank(b"vamp-cpu" + bytes(120), 0, 1)
+        ctx.sampler_init(g["X0"], seed=99, split_block=4)
+        ctx.sampler_set_shard_parts(0, 1, 2)
+        res = ctx.run(5)
+        assert np.array_equal(res["chain"], ref["chain"]) and np.array_equal(res["n_accept"], ref["n_accept"])
+
+
+@pytest.mark.parametrize("voigt,n", [(False, 1), (True, 2)])
+def test_vpfit_facade_on_the_host_abi_matches_oracle(cpu_lib, voigt, n):
+    """VPfit.find_bic / chain_covariance through ctypes and the host ABI against the oracle-backed
+    context: the GPU test of tests/test_gpu_vpfit.py with the host library in place of the HIP one."""
+    import vamp_amd
+    from oracle_ctx import OracleContext
+    from vamp_amd.vpfits import VPfit
+    nu, flux, noise = gv._hi_region(2)
+    g, o = VPfit(seed=3), VPfit(seed=3)
+    g._ctx = vamp_amd.HipContext(lib=cpu_lib)
+    o._ctx = OracleContext()
+    for fit in (g, o):
+        fit.nwalkers = 32
+        fit.find_bic(nu, flux, n, noise, nu.size - 3 * n, voigt=voigt, iterations=20, thin=1, burn=5)
+    assert np.allclose(g._chain_dev, o._chain_dev, rtol=1e-9, atol=1e-12)
+    assert np.allclose(g.bic_array, o.bic_array, rtol=1e-9, atol=0) and np.allclose(g.red_chi_array, o.red_chi_array, rtol=1e-9, atol=0)
+    assert np.allclose(g.chain_covariance(n, voigt=voigt), o.chain_covariance(n, voigt=voigt), rtol=1e-7, atol=0)
+    assert np.allclose(g.total.value, o.total.value, rtol=1e-9, atol=1e-300)

@@ -137,7 +137,11 @@ def _worker(rank, world, port, use_gpu, out_dir, parts=1, block=8):
     from vamp_amd.ensemble import ShardedEnsemble
     dist.init_process_group("gloo", rank=rank, world_size=world)
     region, X0 = _case()
-    if use_gpu:
+    if use_gpu == "cpu_abi":          # the host implementation of the C ABI (oracle/libvamp_cpu.so), bound explicitly
+        import vamp_amd
+        backend = vamp_amd.HipContext(lib=vamp_amd._lib.bind(os.path.join(ROOT, "oracle", "libvamp_cpu.so")))
+        backend.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+    elif use_gpu:
         import vamp_amd
         backend = vamp_amd.HipContext(device=0)
         backend.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
@@ -182,6 +186,19 @@ def test_piecewise_exchange_is_rank_independent_cpu(world, parts, block, tmp_pat
     assert np.array_equal(r["X"], chain[-1])
     assert np.array_equal(r["lnp"], lchain[-1])
     assert np.array_equal(r["nacc"], nacc)
+
+
+@pytest.mark.parametrize("world,parts,block", [(2, 1, 8), (2, 2, 4), (4, 2, 4)])
+def test_sharded_host_abi_matches_oracle_cpu(world, parts, block, tmp_path):
+    """The walker-sharded driver over gloo with the HOST implementation of the C ABI behind ctypes
+    (real set_shard_parts / half_step_part / pack_get / scatter_put calls on every rank): the
+    trajectory of the unsharded oracle sampler, for every world size and piece count."""
+    region, X0 = _case()
+    fn = lambda q: vo.log_prob_batch_fast(region, q)
+    chain, lchain, nacc = vo.run_sampler(fn, X0, fn(X0), 6, seed=4242, block=block)
+    r = _run_ranks(world, "cpu_abi", tmp_path, parts=parts, block=block)
+    assert np.allclose(r["X"], chain[-1], rtol=1e-10, atol=1e-12) and np.array_equal(r["nacc"], nacc)
+    assert np.allclose(r["lnp"], lchain[-1], rtol=1e-9, atol=1e-9)
 
 
 def test_single_rank_pieces_match_run_sampler():

@@ -62,6 +62,18 @@ SIGNATURES = {
 _lib = None
 
 
+def bind(path):
+    """CDLL + prototypes for ANY implementation of the C ABI.  The product only ever binds
+    libvamp_hip.so (``load()``); tests and bench.py's cpu_baseline leg bind the host
+    implementation of the same header (oracle/libvamp_cpu.so) explicitly through this."""
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def load():
     """Load libvamp_hip.so and attach the prototypes.  Raises if it has not been built."""
     global _lib
@@ -71,13 +83,8 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built (run `python -c 'import "
             "__graft_entry__ as g; g.build()'`).  vamp_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = bind(LIB_PATH)
+    return _lib
 
 
 class VampError(RuntimeError):
@@ -86,6 +93,6 @@ class VampError(RuntimeError):
         self.code = code
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        raise VampError(rc, load().vamp_last_error().decode("utf-8", "replace"))
+        raise VampError(rc, (lib or load()).vamp_last_error().decode("utf-8", "replace"))

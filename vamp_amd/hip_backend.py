@@ -50,18 +50,23 @@ def default_split_block(W, world=1):
 class HipContext:
     """One device context: regions + (optionally) an ensemble sampler."""
 
-    def __init__(self, device=0, dtype=F64, wofz_kind=None):
-        self._lib = _lib.load()
+    def __init__(self, device=0, dtype=F64, wofz_kind=None, lib=None):
+        """``lib``: an already bound implementation of the C ABI (``_lib.bind(path)``); the default
+        -- and the only thing the product uses -- is libvamp_hip.so."""
+        self._lib = lib if lib is not None else _lib.load()
         if wofz_kind is None:
             wofz_kind = WOFZ_ACCURATE if dtype == F64 else WOFZ_HUMLICEK_W4
         h = C.c_void_p()
-        _lib.check(self._lib.vamp_ctx_create(C.byref(h), device, dtype, wofz_kind))
+        self._check(self._lib.vamp_ctx_create(C.byref(h), device, dtype, wofz_kind))
         self._h = h
         self.device = device
         self.dtype = dtype
         self.n_regions = 0
         self.ndims = []
         self.W = 0
+
+    def _check(self, rc):
+        _lib.check(rc, self._lib)
 
     # -- lifetime ------------------------------------------------------------------------
     def close(self):
@@ -82,14 +87,14 @@ class HipContext:
         self.close()
 
     def set_stream(self, stream_ptr):
-        _lib.check(self._lib.vamp_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+        self._check(self._lib.vamp_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
 
     def set_stream_default(self):
         """Run on HIP's legacy default stream (what torch uses when no stream is set)."""
-        _lib.check(self._lib.vamp_ctx_set_stream_default(self._h))
+        self._check(self._lib.vamp_ctx_set_stream_default(self._h))
 
     def synchronize(self):
-        _lib.check(self._lib.vamp_ctx_synchronize(self._h))
+        self._check(self._lib.vamp_ctx_synchronize(self._h))
 
     # -- multi-GPU (walker sharding) ---------------------------------------------------------
     def comm_init_rank(self, comm_id, rank, world):
@@ -97,17 +102,17 @@ class HipContext:
         ``rank`` of ``world``; the per-half-step exchange then runs inside the library."""
         if len(comm_id) != 128:
             raise ValueError("comm_id must be the 128 bytes of comm_unique_id()")
-        _lib.check(self._lib.vamp_comm_init_rank(self._h, C.c_char_p(bytes(comm_id)), int(rank), int(world)))
+        self._check(self._lib.vamp_comm_init_rank(self._h, C.c_char_p(bytes(comm_id)), int(rank), int(world)))
 
     def comm_destroy(self):
-        _lib.check(self._lib.vamp_comm_destroy(self._h))
+        self._check(self._lib.vamp_comm_destroy(self._h))
 
     def pack_get(self, part=0):
         """This rank's movers of piece ``part`` after its last half-step: [slots, D + 1]
         (position, lnprob), in slot order (host-staged exchange)."""
         n = self._part_slots
         out = np.empty((n, self.ndims[0] + 1))
-        _lib.check(self._lib.vamp_sampler_pack_get(self._h, int(part), _dp(out)))
+        self._check(self._lib.vamp_sampler_pack_get(self._h, int(part), _dp(out)))
         return out
 
     def scatter_put(self, part, rows_all):
@@ -116,14 +121,14 @@ class HipContext:
         rows_all = _f64(rows_all)
         if rows_all.shape != (self._shard_world * self._part_slots, self.ndims[0] + 1):
             raise ValueError("rows_all must be [world * part_slots, D + 1]")
-        _lib.check(self._lib.vamp_sampler_scatter_put(self._h, int(part), _dp(rows_all)))
+        self._check(self._lib.vamp_sampler_scatter_put(self._h, int(part), _dp(rows_all)))
 
     def set_packing(self, lanes_per_walker):
         """0 = automatic, 16 = four walkers per wavefront (<= 8 components), 64 = one walker per
         wavefront, 65 = one walker per wavefront with its own Taylor tables (<= 8 components),
         256 = one walker per 4-wavefront workgroup (long regions).  Applies from the next
         set_regions call."""
-        _lib.check(self._lib.vamp_ctx_set_packing(self._h, int(lanes_per_walker)))
+        self._check(self._lib.vamp_ctx_set_packing(self._h, int(lanes_per_walker)))
 
     # -- data ----------------------------------------------------------------------------
     def set_regions(self, xs, fluxes, noises, n_comp, mode=MODE_VOIGT4, sample_sd=False, include_norm=False,
@@ -142,7 +147,7 @@ class HipContext:
         nc = np.ascontiguousarray(n_comp, dtype=np.int32)
         b = _f64(bounds).reshape(R, 4) if bounds is not None else None
         z = _f64(nbz).reshape(R, 4) if nbz is not None else None
-        _lib.check(self._lib.vamp_set_regions(
+        self._check(self._lib.vamp_set_regions(
             self._h, R, off.ctypes.data_as(_lib.c_int64_p), _dp(x), _dp(f), _dp(n),
             nc.ctypes.data_as(_lib.c_int32_p), int(mode), int(bool(sample_sd)), int(bool(include_norm)), _dp(b), _dp(z)))
         self.n_regions = R
@@ -150,7 +155,7 @@ class HipContext:
         self.ndims = []
         for r in range(R):
             d = C.c_int(0)
-            _lib.check(self._lib.vamp_region_ndim(self._h, r, C.byref(d)))
+            self._check(self._lib.vamp_region_ndim(self._h, r, C.byref(d)))
             self.ndims.append(d.value)
         self.n_pix = [len(a) for a in xs]
         self.n_comp = [int(k) for k in n_comp]
@@ -165,7 +170,7 @@ class HipContext:
             raise ValueError(f"theta has {D} dims, region {region} needs {self.ndims[region]}")
         out = np.empty(W)
         chi = np.empty(W) if return_chi2 else None
-        _lib.check(self._lib.vamp_lnprob(self._h, region, W, _dp(theta), _dp(out), _dp(chi)))
+        self._check(self._lib.vamp_lnprob(self._h, region, W, _dp(theta), _dp(out), _dp(chi)))
         return (out, chi) if return_chi2 else out
 
     def lnprob_all(self, thetas, return_chi2=False):
@@ -181,7 +186,7 @@ class HipContext:
         flat = np.concatenate([b.ravel() for b in blocks])
         out = np.empty((self.n_regions, W))
         chi = np.empty((self.n_regions, W)) if return_chi2 else None
-        _lib.check(self._lib.vamp_lnprob_all(self._h, W, _dp(flat), _dp(out), _dp(chi)))
+        self._check(self._lib.vamp_lnprob_all(self._h, W, _dp(flat), _dp(out), _dp(chi)))
         return (out, chi) if return_chi2 else out
 
     def map_all(self, starts, iterlim=1000, tol=1e-3, active=None, xtol=1e-4, maxfun=0):
@@ -202,7 +207,7 @@ class HipContext:
             act = np.ascontiguousarray(np.asarray(active, dtype=np.uint8))
             if act.size != self.n_regions:
                 raise ValueError("active needs one flag per region")
-        _lib.check(self._lib.vamp_map_all(self._h, _dp(flat), None if act is None else act.ctypes.data_as(C.c_void_p),
+        self._check(self._lib.vamp_map_all(self._h, _dp(flat), None if act is None else act.ctypes.data_as(C.c_void_p),
                                           int(iterlim), int(maxfun), float(xtol), float(tol), _dp(best), _dp(lnp),
                                           _dp(chi), its.ctypes.data_as(_lib.c_int64_p)))
         offs = np.concatenate([[0], np.cumsum(self.ndims)])
@@ -215,7 +220,7 @@ class HipContext:
         K, P = self.n_comp[region], self.n_pix[region]
         tau = np.empty((K, P))
         flux = np.empty(P)
-        _lib.check(self._lib.vamp_model(self._h, region, _dp(theta1), _dp(tau), _dp(flux)))
+        self._check(self._lib.vamp_model(self._h, region, _dp(theta1), _dp(tau), _dp(flux)))
         return tau, flux
 
     def line_records(self, theta1, region=0):
@@ -225,19 +230,19 @@ class HipContext:
             raise ValueError("theta1 has the wrong length")
         rec = np.empty((self.n_comp[region], 5))
         lp = C.c_double(0.0)
-        _lib.check(self._lib.vamp_line_records(self._h, region, _dp(theta1), _dp(rec), C.byref(lp)))
+        self._check(self._lib.vamp_line_records(self._h, region, _dp(theta1), _dp(rec), C.byref(lp)))
         return rec, lp.value
 
     def wofz_re(self, x, y):
         x = _f64(x).ravel()
         y = _f64(y).ravel()
         out = np.empty_like(x)
-        _lib.check(self._lib.vamp_wofz_re(self._h, x.size, _dp(x), _dp(y), _dp(out)))
+        self._check(self._lib.vamp_wofz_re(self._h, x.size, _dp(x), _dp(y), _dp(out)))
         return out
 
     # -- sampler -------------------------------------------------------------------------
     def sampler_bind_state(self, X_ptr, lnp_ptr):
-        _lib.check(self._lib.vamp_sampler_bind_state(self._h, C.c_void_p(X_ptr), C.c_void_p(lnp_ptr)))
+        self._check(self._lib.vamp_sampler_bind_state(self._h, C.c_void_p(X_ptr), C.c_void_p(lnp_ptr)))
 
     def sampler_init(self, theta0, seed=0, a=2.0, split_block=None):
         """theta0: array [W, D] (single region) or list of [W, D_r] arrays."""
@@ -251,7 +256,7 @@ class HipContext:
         if split_block is None:
             split_block = default_split_block(W)
         flat = _f64(np.concatenate([_f64(b).ravel() for b in blocks]))
-        _lib.check(self._lib.vamp_sampler_init(self._h, W, _dp(flat), C.c_uint64(seed & (2**64 - 1)), float(a), int(split_block)))
+        self._check(self._lib.vamp_sampler_init(self._h, W, _dp(flat), C.c_uint64(seed & (2**64 - 1)), float(a), int(split_block)))
         self.W = W
         self.split_block = split_block
         self.total_theta = flat.size
@@ -265,7 +270,7 @@ class HipContext:
         the list of (own_begin, own_end) row ranges, one per piece."""
         b = (C.c_int64 * parts)()
         e = (C.c_int64 * parts)()
-        _lib.check(self._lib.vamp_sampler_set_shard_parts(self._h, rank, world, parts, b, e))
+        self._check(self._lib.vamp_sampler_set_shard_parts(self._h, rank, world, parts, b, e))
         self._shard_world = world
         self._part_slots = (int(e[0]) - int(b[0])) // 2      # half of every owned split chunk moves per half-step
         return [(int(b[i]), int(e[i])) for i in range(parts)]
@@ -273,21 +278,21 @@ class HipContext:
     def sampler_state_ptrs(self):
         X, L = C.c_void_p(), C.c_void_p()
         tt, tw = C.c_int64(0), C.c_int64(0)
-        _lib.check(self._lib.vamp_sampler_state_ptrs(self._h, C.byref(X), C.byref(L), C.byref(tt), C.byref(tw)))
+        self._check(self._lib.vamp_sampler_state_ptrs(self._h, C.byref(X), C.byref(L), C.byref(tt), C.byref(tw)))
         return X.value, L.value, tt.value, tw.value
 
     def half_step(self, half):
-        _lib.check(self._lib.vamp_sampler_half_step(self._h, int(half)))
+        self._check(self._lib.vamp_sampler_half_step(self._h, int(half)))
 
     def half_step_part(self, half, part):
-        _lib.check(self._lib.vamp_sampler_half_step_part(self._h, int(half), int(part)))
+        self._check(self._lib.vamp_sampler_half_step_part(self._h, int(half), int(part)))
 
     def half_step_ext(self, active, partner, zz, logu, region=0):
         a = np.ascontiguousarray(active, dtype=np.int32)
         p = np.ascontiguousarray(partner, dtype=np.int32)
         z = _f64(zz)
         u = _f64(logu)
-        _lib.check(self._lib.vamp_sampler_half_step_ext(
+        self._check(self._lib.vamp_sampler_half_step_ext(
             self._h, region, a.size, a.ctypes.data_as(_lib.c_int32_p), p.ctypes.data_as(_lib.c_int32_p), _dp(z), _dp(u)))
 
     def _split(self, flat, per_walker):
@@ -308,7 +313,7 @@ class HipContext:
         lchain = np.empty((n_keep, self.total_walkers)) if store_chain else None
         nacc = np.empty(self.total_walkers, dtype=np.int64)
         sec = C.c_double(0.0)
-        _lib.check(self._lib.vamp_sampler_run(self._h, n_steps, thin, _dp(chain), _dp(lchain),
+        self._check(self._lib.vamp_sampler_run(self._h, n_steps, thin, _dp(chain), _dp(lchain),
                                               nacc.ctypes.data_as(_lib.c_int64_p), C.byref(sec)))
         res = {"seconds": sec.value, "n_accept": nacc if self.n_regions == 1 else self._split(nacc, True)}
         if store_chain:
@@ -322,7 +327,7 @@ class HipContext:
         ``tensor.data_ptr()``): chain [n_keep, total_theta], lnprob [n_keep, total_walkers].
         Returns the seconds spent in the sampling loop."""
         sec = C.c_double(0.0)
-        _lib.check(self._lib.vamp_sampler_run_dev(self._h, int(n_steps), int(thin), C.c_void_p(chain_ptr or 0),
+        self._check(self._lib.vamp_sampler_run_dev(self._h, int(n_steps), int(thin), C.c_void_p(chain_ptr or 0),
                                                   C.c_void_p(lnprob_ptr or 0), C.byref(sec)))
         return sec.value
 
@@ -331,7 +336,7 @@ class HipContext:
         lp = np.empty(self.total_walkers)
         na = np.empty(self.total_walkers, dtype=np.int64)
         st = C.c_int64(0)
-        _lib.check(self._lib.vamp_sampler_get_state(self._h, _dp(th), _dp(lp), na.ctypes.data_as(_lib.c_int64_p), C.byref(st)))
+        self._check(self._lib.vamp_sampler_get_state(self._h, _dp(th), _dp(lp), na.ctypes.data_as(_lib.c_int64_p), C.byref(st)))
         X = self._split(th, False)
         L = self._split(lp, True)
         if self.n_regions == 1:
@@ -343,10 +348,10 @@ class HipContext:
         lps = [lnprob] if isinstance(lnprob, np.ndarray) else list(lnprob)
         th = _f64(np.concatenate([_f64(b).ravel() for b in blocks]))
         lp = _f64(np.concatenate([_f64(b).ravel() for b in lps]))
-        _lib.check(self._lib.vamp_sampler_set_state(self._h, _dp(th), _dp(lp), int(step)))
+        self._check(self._lib.vamp_sampler_set_state(self._h, _dp(th), _dp(lp), int(step)))
 
     def kernel_timing(self, enable=True):
         ms = C.c_double(0.0)
         n = C.c_int64(0)
-        _lib.check(self._lib.vamp_kernel_timing(self._h, int(enable), C.byref(ms), C.byref(n)))
+        self._check(self._lib.vamp_kernel_timing(self._h, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
