@@ -104,6 +104,12 @@ int vamp_set_regions(vamp_ctx* ctx, int n_regions, const int64_t* pix_off, const
                      const double* flux, const double* noise, const int32_t* n_comp, int mode,
                      int sample_sd, int include_norm, const double* bounds, const double* nbz);
 
+/* Identity of every region in the sampler's draw keys (default: its index in this context).  A
+ * spectrum whose regions are spread over several contexts / devices (independent posteriors: no
+ * collective, SURVEY 8e "Multi-region") passes each region's index in the WHOLE spectrum, and every
+ * region then follows the chain it follows in the single-context batch. */
+int vamp_set_region_ids(vamp_ctx* ctx, const int32_t* ids);
+
 /* number of sampled dimensions of a region (q*K, +1 with sample_sd) */
 int vamp_region_ndim(vamp_ctx* ctx, int region, int* ndim);
 

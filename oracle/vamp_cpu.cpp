@@ -50,7 +50,7 @@ int fail(int code, const std::string& msg) {
 
 struct Region {
     long long pix_off = 0, theta_off = 0, walker_off = 0, d_before = 0;
-    int P = 0, K = 0, mode = 0, D = 0, q = 0, sample_sd = 0;
+    int P = 0, K = 0, mode = 0, D = 0, q = 0, sample_sd = 0, rng_id = 0;
     double c_lo = 0, c_hi = 0, w_max = 0, lp_c = 0, lp_w = 0;
     double l_fixed = 0, line = 0, x_origin = 0, x_scale = 1, norm_const = 0;
 };
@@ -242,15 +242,16 @@ Move draw_move(const vamp_ctx* c, unsigned step, int half, int region, long long
     const uint32_t hb = (uint32_t)(c->split_block / 2);
     const uint32_t chunk = (uint32_t)(a_loc / hb), pos = (uint32_t)(a_loc % hb);
     Move d;
-    d.ws = (long long)chunk * c->split_block + split_perm(c->seed, step, chunk, (uint32_t)region, pos + (half ? hb : 0u), (uint32_t)c->split_block);
-    const long long gid = c->R[region].walker_off + d.ws;
+    const uint32_t rid = (uint32_t)c->R[region].rng_id;      // the region's identity in the draw keys
+    d.ws = (long long)chunk * c->split_block + split_perm(c->seed, step, chunk, rid, pos + (half ? hb : 0u), (uint32_t)c->split_block);
+    const long long gid = (long long)rid * c->W + d.ws;
     const uint32_t k0 = (uint32_t)c->seed, k1 = (uint32_t)(c->seed >> 32);
     const U4 r = philox({(uint32_t)gid, step, ((uint32_t)half << 8) | STREAM_MOVE, (uint32_t)((uint64_t)gid >> 32)}, k0, k1);
     const double t = (c->a - 1.0) * u53(r.c0, r.c1) + 1.0;
     d.z = t * t / c->a;
     const uint64_t j = (uint64_t)(((unsigned __int128)(((uint64_t)r.c2 << 32) | r.c3) * (unsigned __int128)(uint64_t)halfW) >> 64);
     const uint32_t cchunk = (uint32_t)(j / hb), cpos = (uint32_t)(j % hb);
-    d.wc = (long long)cchunk * c->split_block + split_perm(c->seed, step, cchunk, (uint32_t)region, cpos + (half ? 0u : hb), (uint32_t)c->split_block);
+    d.wc = (long long)cchunk * c->split_block + split_perm(c->seed, step, cchunk, rid, cpos + (half ? 0u : hb), (uint32_t)c->split_block);
     const U4 r2 = philox({(uint32_t)gid, step, ((uint32_t)half << 8) | STREAM_ACCEPT, (uint32_t)((uint64_t)gid >> 32)}, k0, k1);
     const double u2 = u53(r2.c0, r2.c1);
     d.logu = u2 > 0.0 ? std::log(u2) : NEG_INF;
@@ -322,7 +323,7 @@ void scatter_part(vamp_ctx* c, int part, const double* rows) {
         if (i >= own_lo && i < own_lo + c->part_slots) continue;
         const long long slot = (long long)part * c->part_stride + i;
         const uint32_t chunk = (uint32_t)(slot / hb), pos = (uint32_t)(slot % hb);
-        const long long ws = (long long)chunk * c->split_block + split_perm(c->seed, step, chunk, 0u, pos + (half ? hb : 0u), (uint32_t)c->split_block);
+        const long long ws = (long long)chunk * c->split_block + split_perm(c->seed, step, chunk, (uint32_t)R.rng_id, pos + (half ? hb : 0u), (uint32_t)c->split_block);
         const double* src = rows + i * (R.D + 1);
         std::memcpy(c->X + R.theta_off + ws * R.D, src, R.D * sizeof(double));
         c->lnp[R.walker_off + ws] = src[R.D];
@@ -403,6 +404,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         d.pix_off = pix_off[r];
         d.P = (int)P; d.K = n_comp[r]; d.mode = mode; d.q = q; d.sample_sd = sample_sd ? 1 : 0;
         d.D = q * d.K + d.sample_sd;
+        d.rng_id = r;
         d.d_before = r ? R[r - 1].d_before + R[r - 1].D : 0;
         const double* xr = x + pix_off[r];
         if (bounds) {
@@ -446,6 +448,15 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
     c->R = R;
     c->mode = mode;
     c->n_regions = n_regions;
+    return VAMP_OK;
+}
+
+int vamp_set_region_ids(vamp_ctx* c, const int32_t* ids) {
+    if (!c || !ids) return fail(VAMP_ERR_ARG, "vamp_set_region_ids: NULL argument");
+    if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_set_region_ids: call vamp_set_regions first");
+    for (int r = 0; r < c->n_regions; ++r)
+        if (ids[r] < 0) return fail(VAMP_ERR_ARG, "vamp_set_region_ids: ids must be >= 0");
+    for (int r = 0; r < c->n_regions; ++r) c->R[r].rng_id = ids[r];
     return VAMP_OK;
 }
 

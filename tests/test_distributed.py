@@ -201,6 +201,87 @@ def test_sharded_host_abi_matches_oracle_cpu(world, parts, block, tmp_path):
     assert np.allclose(r["lnp"], lchain[-1], rtol=1e-9, atol=1e-9)
 
 
+def _region_batch_case():
+    g = load_golden("lnprob_cases.npz")
+    names = [f"H1215_r{i}_K{k}_m1_sd0" for i, k in ((0, 1), (1, 4), (2, 1), (0, 4), (2, 4))]
+    xs, fs, ns = [g[n + "_x"] for n in names], [g[n + "_flux"] for n in names], [g[n + "_noise"] for n in names]
+    ks = [1, 4, 1, 4, 4]
+    rng = np.random.default_rng(12)
+    th = []
+    for x, k in zip(xs, ks):
+        t = np.empty((16, 4 * k))
+        for j in range(k):
+            t[:, 4 * j:4 * j + 4] = np.stack([rng.uniform(0.3, 1.5, 16), rng.uniform(x[2], x[-3], 16), rng.uniform(0.5, 3, 16),
+                                              rng.uniform(2, 8, 16)], 1)
+        th.append(t)
+    return xs, fs, ns, ks, th
+
+
+def _region_worker(rank, world, port, kind, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import vamp_amd
+    from vamp_amd.ensemble import RegionShardedBatch
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    xs, fs, ns, ks, th = _region_batch_case()
+    lib = vamp_amd._lib.bind(os.path.join(ROOT, "oracle", "libvamp_cpu.so")) if kind == "cpu_abi" else None
+    ctx = vamp_amd.HipContext(device=0, lib=lib)
+    batch = RegionShardedBatch(ctx, xs, fs, ns, ks, th, seed=31337, mode=vamp_amd.MODE_VOIGT4, dist=dist, split_block=8)
+    assert sorted(sum(batch.assignment, [])) == list(range(5)) and batch.mine == batch.assignment[rank]
+    mine, _ = batch.run(5)
+    allres = batch.gather(mine)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "regions.npz"), **{f"chain_{r}": v["chain"] for r, v in allres.items()},
+                 **{f"nacc_{r}": v["n_accept"] for r, v in allres.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_region_batch(kind, tmp_path):
+    import torch.multiprocessing as mp
+    import vamp_amd
+    mp.spawn(_region_worker, args=(2, _free_port(), kind, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "regions.npz"))
+    xs, fs, ns, ks, th = _region_batch_case()
+    lib = vamp_amd._lib.bind(os.path.join(ROOT, "oracle", "libvamp_cpu.so")) if kind == "cpu_abi" else None
+    with vamp_amd.HipContext(device=0, lib=lib) as ctx:           # the single-context batch of all five regions
+        ctx.set_regions(xs, fs, ns, ks, mode=vamp_amd.MODE_VOIGT4)
+        ctx.sampler_init(th, seed=31337, split_block=8)
+        ref = ctx.run(5)
+    for r in range(5):
+        assert np.array_equal(got[f"chain_{r}"], ref["chain"][r]), r          # same library, same draws: bit for bit
+        assert np.array_equal(got[f"nacc_{r}"], ref["n_accept"][r]), r
+        reg = vo.Region(x=xs[r], flux=fs[r], noise=ns[r], n_comp=ks[r], mode=vo.MODE_VOIGT4)
+        fn = lambda q, reg=reg: vo.log_prob_batch(reg, q)
+        chain, _, nacc = vo.run_sampler(fn, th[r], fn(th[r]), 5, seed=31337, block=8, region=r, walker_off=r * 16)
+        assert np.allclose(got[f"chain_{r}"], chain, rtol=1e-10, atol=1e-12) and np.array_equal(got[f"nacc_{r}"], nacc), r
+
+
+def test_region_sharded_batch_matches_single_context_cpu(tmp_path):
+    """BASELINE.json config 3 on several devices: independent regions spread over 2 ranks (balanced by
+    W * P * K, no collective), each rank its own context of the host ABI.  Every region's chain equals
+    the one it has in the single-context batch of all regions, and the oracle's."""
+    _check_region_batch("cpu_abi", tmp_path)
+
+
+@pytest.mark.gpu
+def test_region_sharded_batch_matches_single_context_gpu(tmp_path):
+    """the same with the HIP kernels (both ranks on device 0)"""
+    _check_region_batch("hip", tmp_path)
+
+
+def test_shard_regions_balances_and_is_deterministic():
+    from vamp_amd.ensemble import shard_regions
+    costs = [5, 1, 1, 1, 9, 3, 3, 2]
+    for world in (1, 2, 3, 8):
+        parts = shard_regions(costs, world)
+        assert sorted(sum(parts, [])) == list(range(8)) and parts == shard_regions(costs, world)
+        loads = [sum(costs[r] for r in p) for p in parts]
+        assert max(loads) <= max(max(costs), -(-sum(costs) // world) + max(costs) // 2)
+
+
 def test_single_rank_pieces_match_run_sampler():
     from vamp_amd.ensemble import ShardedEnsemble
     region, X0 = _case()

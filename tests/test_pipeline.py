@@ -199,3 +199,71 @@ def test_fit_spectrum_batched_matches_sequential_shape(tmp_path):
         assert len(r.fit.bic_array) == 3 and np.all(np.isfinite(r.fit.bic_array))
         assert r.fit.total.value.shape == r.flux_array.shape
     assert np.all(sp.flux_model["total"] <= 1.0 + 1e-12)
+
+
+def test_do_vamp_parallel_plan_and_worker_pinning(tmp_path, monkeypatch):
+    """The folder branch of do_vamp (reference do_vamp.py:64-96, which never ran): files are dealt
+    round-robin to min(parallel, files) spawned workers, worker r is pinned to GPU r % gpus through
+    HIP_VISIBLE_DEVICES before the HIP library is loaded in that process, every file is fitted once;
+    --parallel 1 on a folder walks the files in-process."""
+    import json
+    from vamp_amd import do_vamp
+    files = ["f%d" % i for i in range(5)]
+    assert do_vamp.plan_workers(files, 2, 8) == [(0, ["f0", "f2", "f4"]), (1, ["f1", "f3"])]
+    assert do_vamp.plan_workers(files, 8, 2) == [(0, ["f0"]), (1, ["f1"]), (0, ["f2"]), (1, ["f3"]), (0, ["f4"])]
+    assert do_vamp.plan_workers(files[:1], 4, 4) == [(0, ["f0"])]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3,5")
+    assert do_vamp.visible_gpus() == 2
+    folder, out = tmp_path / "spectra", tmp_path / "out"
+    folder.mkdir()
+    for i in range(5):
+        (folder / ("spectrum_%d.npz" % i)).write_bytes(b"")
+    (folder / "notes.txt").write_text("ignored")
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    rc = do_vamp.main([str(folder), "1215.67", "--output_folder", str(out), "--parallel", "3"], _fit_name="parallel_probe:record_fit")
+    assert rc == 0
+    recs = [json.load(open(os.path.join(str(out), f))) for f in sorted(os.listdir(str(out)))]
+    assert sorted(r["file"] for r in recs) == ["spectrum_%d.npz" % i for i in range(5)]
+    by_pid = {}
+    for r in recs:
+        by_pid.setdefault(r["pid"], []).append(r)
+        assert not r["lib_loaded_before_fit"] and r["device_arg"] == 0 and not r["torch_imported"]
+    assert len(by_pid) == 3                                              # three workers
+    # worker r took files r, r+3 and GPU r % 2 of the visible list "3,5"
+    want = {("spectrum_0.npz", "spectrum_3.npz"): "3", ("spectrum_1.npz", "spectrum_4.npz"): "5", ("spectrum_2.npz",): "3"}
+    got = {tuple(sorted(r["file"] for r in rs)): rs[0]["hip_visible"] for rs in by_pid.values()}
+    assert got == want
+    # --parallel 1: same files, this process, no pinning
+    seen = []
+    monkeypatch.setattr(do_vamp, "fit_one", lambda path, args, device=0: seen.append(os.path.basename(path)))
+    assert do_vamp.main([str(folder), "1215.67", "--parallel", "1"]) == 0
+    assert seen == ["spectrum_%d.npz" % i for i in range(5)]
+
+
+@pytest.mark.gpu
+def test_do_vamp_folder_parallel_equals_sequential(tmp_path):
+    """Two spectra in a folder: --parallel 2 (two spawned workers sharing the one GPU) writes the same
+    result files as --parallel 1."""
+    from vamp_amd import h5min
+    g = load_golden("simba_spectra.npz")
+    folder = tmp_path / "spectra"
+    folder.mkdir()
+    for i, tag in enumerate(("CII1036", "H1215")):
+        h5min.write(str(folder / ("spectrum_%d.h5" % i)), {k: g[tag + "_" + k] for k in ("wavelength", "flux", "noise")})
+    env = dict(os.environ, PYTHONPATH=ROOT, MPLBACKEND="Agg")
+    outs = []
+    for par in ("1", "2"):
+        out = tmp_path / ("out" + par)
+        rc = subprocess.run([sys.executable, "-m", "vamp_amd.do_vamp", str(folder), "1215.67", "--output_folder", str(out),
+                             "--parallel", par, "--gpus", "1", "--conv_attempts", "1", "--walkers", "32", "--iterations", "200",
+                             "--burn", "50", "--thin", "5", "--seed", "3", "--batched"], env=env, capture_output=True, text=True,
+                            timeout=900)
+        assert rc.returncode == 0, rc.stderr[-2000:]
+        outs.append(out)
+    names = sorted(f for f in os.listdir(outs[0]) if f.endswith(".h5"))
+    assert names == sorted(f for f in os.listdir(outs[1]) if f.endswith(".h5")) and len(names) == 4
+    for f in names:
+        a, b = h5min.read(str(outs[0] / f)), h5min.read(str(outs[1] / f))
+        assert set(a) == set(b)
+        for k in a:
+            assert np.array_equal(a[k], b[k], equal_nan=True), (f, k)

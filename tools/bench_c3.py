@@ -3,6 +3,8 @@
 sampled in ONE batched launch per half-step, <= 8 Voigt components each.
 
     python tools/bench_c3.py [--walkers 16384] [--steps 5] [--dtype f64|f32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_c3.py ...
+        (N GPUs: the regions are spread over the ranks by W * P * K, no collective -- vamp_amd.ensemble.RegionShardedBatch)
 
 Regions and the spectrum come from tests/golden/q1422_spectrum.npz (the reference's
 vamp_1.0/data/q1422.cont and the detector of vpspectrum.py:67-175)."""
@@ -57,18 +59,42 @@ def main():
     a = ap.parse_args()
     import vamp_amd
     xs, fs, ns, ks = build_regions()
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     rng = np.random.default_rng(1422)
-    ctx = vamp_amd.HipContext(device=0, dtype=vamp_amd.F64 if a.dtype == "f64" else vamp_amd.F32)
-    ctx.set_packing(a.packing)
-    ctx.set_regions(xs, fs, ns, ks, mode=vamp_amd.MODE_VOIGT4)
     theta0 = [start_walkers(rng, x, k, a.walkers) for x, k in zip(xs, ks)]
-    ctx.sampler_init(theta0, seed=1422, split_block=vamp_amd.default_split_block(a.walkers))
-    ctx.run(a.warmup, store_chain=False)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist          # host-side bootstrap / barrier only (gloo)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    ctx = vamp_amd.HipContext(device=local, dtype=vamp_amd.F64 if a.dtype == "f64" else vamp_amd.F32)
+    ctx.set_packing(a.packing)
+    from vamp_amd.ensemble import RegionShardedBatch
+    batch = RegionShardedBatch(ctx, xs, fs, ns, ks, theta0, seed=1422, mode=vamp_amd.MODE_VOIGT4, dist=dist,
+                               split_block=vamp_amd.default_split_block(a.walkers))
+    batch.run(a.warmup, store_chain=False)
+    if dist is not None:
+        dist.barrier()
     ctx.kernel_timing(True)
     t0 = time.perf_counter()
-    res = ctx.run(a.steps, store_chain=False)
+    mine, _ = batch.run(a.steps, store_chain=False)
+    ctx.synchronize()
+    if dist is not None:
+        dist.barrier()
     dt = time.perf_counter() - t0
     ms, n = ctx.kernel_timing(False)
+    acc_mine = [float(v["n_accept"].mean()) for v in mine.values()]
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+        box = [None] * world
+        dist.all_gather_object(box, acc_mine)
+        acc_mine = sum(box, [])
+    if rank != 0:
+        return
     R = len(xs)
     P = np.array([len(x) for x in xs])
     K = np.array(ks)
@@ -76,11 +102,12 @@ def main():
     s = 8 if a.dtype == "f64" else 4
     b_alg = float(np.sum(a.walkers * (3 * P + 3 * D + 2) * s))          # per step, all regions
     evals = float(np.sum(a.walkers * P * K))
-    acc = np.mean([x.mean() for x in res["n_accept"]]) / (a.steps + a.warmup)
+    acc = np.mean(acc_mine) / (a.steps + a.warmup)
     print(json.dumps({"config": "q1422: %d regions, sum P = %d, sum K = %d, W = %d per region, %s" % (R, P.sum(), K.sum(), a.walkers, a.dtype),
+                      "n_gpus": world, "regions_on_rank0": len(batch.mine),
                       "region_walker_steps_per_s": R * a.walkers * a.steps / dt, "ms_per_step": dt / a.steps * 1e3,
                       "avg_launch_ms": ms / max(1, n), "faddeeva_gevals_per_s": evals * a.steps / dt / 1e9,
-                      "algorithmic_GBps": b_alg * a.steps / dt / 1e9, "hbm_frac": b_alg * a.steps / dt / 8e12,
+                      "algorithmic_GBps": b_alg * a.steps / dt / 1e9, "hbm_frac": b_alg * a.steps / dt / 8e12 / world,
                       "acceptance_fraction": float(acc), "packing": a.packing}))
 
 

@@ -18,10 +18,11 @@ ap.add_argument("--burn", type=int, default=200)
 ap.add_argument("--walkers", type=int, default=32)
 ap.add_argument("--max-regions", type=int, default=0)
 ap.add_argument("--voigt", action="store_true")
+ap.add_argument("--attempts", type=int, default=4)
 a = ap.parse_args()
 from vamp_amd.vpspectrum import VPspectrum
 q = np.load(os.path.join(ROOT, "tests", "golden", "q1422_spectrum.npz"))
-sp = VPspectrum(1215.67, voigt=a.voigt, nwalkers=a.walkers, iterations=a.iterations, thin=5, burn=a.burn, seed=1, verbose=True)
+sp = VPspectrum(1215.67, voigt=a.voigt, convergence_attempts=a.attempts, nwalkers=a.walkers, iterations=a.iterations, thin=5, burn=a.burn, seed=1, verbose=True)
 wl, fl, no = q["wavelength_milli"] / 1000.0, q["flux_micro"] / 1e6, q["noise_micro"] / 1e6
 if a.max_regions:
     end = int(q["region_pixels"][a.max_regions - 1][1]) + 50

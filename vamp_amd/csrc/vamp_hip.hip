@@ -81,7 +81,7 @@ struct RegionDev {
     long long walker_off;  // first global walker id of this region in the sampler state
     long long d_before;    // sum of D over the preceding regions (vamp_lnprob_all: block r starts at W * d_before)
     int P, K, mode, D;     // D = q*K (+1 if sample_sd)
-    int sample_sd, q, pad0, pad1;
+    int sample_sd, q, rng_id, pad1;   // rng_id: the region's identity in the draw keys (default: its index)
     double c_lo, c_hi;     // centroid prior (vpfits.py:250,293)
     double w_max;          // sigma_max (GAUSS3, vpfits.py:320) or fwhm_max (vpfits.py:326)
     double lp_c, lp_w;     // -log(c_hi - c_lo), -log(w_max): uniform log-densities
@@ -1182,9 +1182,12 @@ __device__ __forceinline__ MoveDraw draw_move(const SamplerDev& S, unsigned step
     const unsigned chunk = (unsigned)(a_loc / hb);
     const unsigned pos = (unsigned)(a_loc % hb);
     MoveDraw d;
+    // draws are keyed by the region's rng_id, not by its position in this context: a region follows
+    // the same trajectory whichever device (and whichever subset of a spectrum's regions) holds it
+    const unsigned rid = (unsigned)S.regions[region].rng_id;
     d.ws = (long long)chunk * S.split_block +
-           split_perm(S.seed, step, chunk, (unsigned)region, pos + (half ? hb : 0u), (unsigned)S.split_block);
-    const long long gid = S.regions[region].walker_off + d.ws;
+           split_perm(S.seed, step, chunk, rid, pos + (half ? hb : 0u), (unsigned)S.split_block);
+    const long long gid = (long long)rid * S.W + d.ws;
     const unsigned k0 = (unsigned)S.seed, k1 = (unsigned)(S.seed >> 32);
     const U4 r = philox4x32_10({(unsigned)gid, step, ((unsigned)half << 8) | STREAM_MOVE, (unsigned)(gid >> 32)}, k0, k1);
     const double u1 = u53(r.c0, r.c1);
@@ -1194,7 +1197,7 @@ __device__ __forceinline__ MoveDraw draw_move(const SamplerDev& S, unsigned step
     const unsigned cchunk = (unsigned)(j / hb);
     const unsigned cpos = (unsigned)(j % hb);
     d.wc = (long long)cchunk * S.split_block +
-           split_perm(S.seed, step, cchunk, (unsigned)region, cpos + (half ? 0u : hb), (unsigned)S.split_block);
+           split_perm(S.seed, step, cchunk, rid, cpos + (half ? 0u : hb), (unsigned)S.split_block);
     const U4 r2 = philox4x32_10({(unsigned)gid, step, ((unsigned)half << 8) | STREAM_ACCEPT, (unsigned)(gid >> 32)}, k0, k1);
     const double u2 = u53(r2.c0, r2.c1);
     d.logu = u2 > 0.0 ? log(u2) : NEG_INF;
@@ -1329,7 +1332,7 @@ __global__ __launch_bounds__(256) void k_scatter_rows(SamplerDev S, const double
     const unsigned hb = (unsigned)(S.split_block >> 1);
     const unsigned chunk = (unsigned)(slot / hb), pos = (unsigned)(slot % hb);
     const long long ws = (long long)chunk * S.split_block +
-                         split_perm(S.seed, step, chunk, 0u, pos + (half ? hb : 0u), (unsigned)S.split_block);
+                         split_perm(S.seed, step, chunk, (unsigned)R.rng_id, pos + (half ? hb : 0u), (unsigned)S.split_block);
     const double* src = recv + i * (long long)(D + 1);
     double* dst = S.X + R.theta_off + ws * D;
     for (int d = l; d < D; d += 16) dst[d] = src[d];
@@ -1919,6 +1922,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         d.mode = mode;
         d.q = q;
         d.sample_sd = sample_sd ? 1 : 0;
+        d.rng_id = r;
         d.D = q * d.K + d.sample_sd;
         d.d_before = r ? R[r - 1].d_before + R[r - 1].D : 0;
         const double* xr = x + pix_off[r];
@@ -2031,6 +2035,18 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
     c->mode = mode;
     c->n_regions = n_regions;
     c->n_pix = N;
+    return VAMP_OK;
+}
+
+int vamp_set_region_ids(vamp_ctx* c, const int32_t* ids) {
+    if (!c || !ids) return fail(VAMP_ERR_ARG, "vamp_set_region_ids: NULL argument");
+    if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_set_region_ids: call vamp_set_regions first");
+    for (int r = 0; r < c->n_regions; ++r)
+        if (ids[r] < 0) return fail(VAMP_ERR_ARG, "vamp_set_region_ids: ids must be >= 0");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < c->n_regions; ++r) c->regions_h[r].rng_id = ids[r];
+    HIP_TRY(hipMemcpy(c->regions_d, c->regions_h.data(), c->n_regions * sizeof(RegionDev), hipMemcpyHostToDevice));
     return VAMP_OK;
 }
 

@@ -2,15 +2,47 @@
 
     python -m vamp_amd.do_vamp data_file line [--output_folder DIR] [--voigt] [--parallel N] [--conv_attempts N]
 
-``data_file`` is one spectrum, or (with --parallel) a folder of ``spectrum_*.h5`` files that are
-distributed over the visible GPUs, one worker process per GPU (the reference's mp.Pool branch,
-do_vamp.py:64-96, calls an undefined function and never ran).  New flags: --walkers, --iterations,
---burn, --thin, --seed, --gpus.
+``data_file`` is one spectrum, or a folder of ``spectrum_*.h5`` / ``spectrum_*.npz`` files.  With
+``--parallel N`` the files of a folder are dealt to N worker processes (the reference's mp.Pool
+branch, do_vamp.py:64-96, calls an undefined function and never ran); worker r runs on GPU
+``r % gpus`` and pins it with HIP_VISIBLE_DEVICES before anything in that process touches HIP.
+Spectra are independent: no communication.  New flags: --walkers, --iterations, --burn, --thin,
+--seed, --batched, --gpus (GPUs to use; default: the GPUs this process can see).
 """
 import argparse
 import glob
+import importlib
 import os
 import sys
+
+
+def visible_gpus():
+    """Number of GPUs a worker may be pinned to, found WITHOUT initialising HIP in this process (the
+    workers are spawned afterwards): HIP_VISIBLE_DEVICES if set, else the KFD topology nodes that
+    have SIMDs (CPUs are nodes too, with simd_count 0); at least 1."""
+    env = os.environ.get("HIP_VISIBLE_DEVICES")
+    if env is not None and env.strip() != "":
+        return max(1, len([t for t in env.split(",") if t.strip() != ""]))
+    n = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(prop):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def spectrum_files(folder):
+    return sorted(glob.glob(os.path.join(folder, "spectrum_*.h5")) + glob.glob(os.path.join(folder, "spectrum_*.npz")))
+
+
+def plan_workers(files, parallel, gpus):
+    """[(device, [files...]), ...]: at most ``parallel`` workers, none without a file; worker r
+    takes files r, r + n, r + 2n, ... and GPU r % gpus."""
+    n = max(1, min(int(parallel), len(files)))
+    return [(r % max(1, int(gpus)), files[r::n]) for r in range(n)]
 
 
 def fit_one(path, args, device=0):
@@ -21,19 +53,24 @@ def fit_one(path, args, device=0):
     return spec.fit_spectrum(batched=args.batched)
 
 
-def _worker(rank, files, args):
-    os.environ["HIP_VISIBLE_DEVICES"] = str(rank)         # before any HIP call in this process
+def _worker(device, files, args, fit_name):
+    # pin the GPU first: nothing imported so far in this (spawned) process has touched HIP
+    visible = [t.strip() for t in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if t.strip() != ""]
+    os.environ["HIP_VISIBLE_DEVICES"] = visible[device] if device < len(visible) else str(device)
+    mod, _, fn = fit_name.partition(":")
+    fit = getattr(importlib.import_module(mod), fn)
     for f in files:
-        fit_one(f, args, device=0)
+        fit(f, args, device=0)
 
 
-def main(argv=None):
+def main(argv=None, _fit_name="vamp_amd.do_vamp:fit_one"):
     p = argparse.ArgumentParser(description="Voigt Automatic MCMC Profiles on MI355X")
     p.add_argument("data_file", help="spectrum file (HDF5 / npz / 4-column text), or a folder with --parallel")
     p.add_argument("line", type=float, help="rest wavelength of the absorption line [Angstrom]")
     p.add_argument("--output_folder", default=None, help="folder for plots and result files")
     p.add_argument("--voigt", action="store_true", help="fit Voigt profiles (default: Gaussian)")
-    p.add_argument("--parallel", type=int, default=1, help="number of worker processes (one GPU each)")
+    p.add_argument("--parallel", type=int, default=1, help="worker processes for a folder of spectra (worker r on GPU r %% gpus)")
+    p.add_argument("--gpus", type=int, default=0, help="GPUs to spread the workers over (default: all visible)")
     p.add_argument("--conv_attempts", type=int, default=10, help="fit attempts per region")
     p.add_argument("--walkers", type=int, default=None)
     p.add_argument("--iterations", type=int, default=3000)
@@ -47,16 +84,20 @@ def main(argv=None):
         os.makedirs(args.output_folder, exist_ok=True)
         if not args.output_folder.endswith(os.sep):
             args.output_folder += os.sep
-    if args.parallel <= 1 or os.path.isfile(args.data_file):
+    if os.path.isfile(args.data_file):
         fit_one(args.data_file, args)
         return 0
-    files = sorted(glob.glob(os.path.join(args.data_file, "spectrum_*.h5")) +
-                   glob.glob(os.path.join(args.data_file, "spectrum_*.npz")))
+    files = spectrum_files(args.data_file)
     if not files:
         sys.exit("no spectrum_* files in " + args.data_file)
+    if args.parallel <= 1:
+        for f in files:                      # one process, one GPU, one spectrum after the other
+            fit_one(f, args)
+        return 0
+    gpus = args.gpus if args.gpus else visible_gpus()
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, files[r::args.parallel], args)) for r in range(args.parallel)]
+    procs = [ctx.Process(target=_worker, args=(dev, fs, args, _fit_name)) for dev, fs in plan_workers(files, args.parallel, gpus)]
     for pr in procs:
         pr.start()
     rc = 0

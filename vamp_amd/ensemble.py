@@ -54,6 +54,64 @@ def shard_regions(costs, world):
     return [sorted(v) for v in out]
 
 
+class RegionShardedBatch:
+    """The independent regions of one spectrum spread over the ranks of ``dist`` (BASELINE.json
+    config 3 on several GPUs; SURVEY 8e "Multi-region"): every rank samples its own regions in its own
+    context, there is NO collective in the data path, and ``dist`` is only used to hand results
+    round afterwards.  Regions are assigned by ``shard_regions`` on the cost W * P * K; every region
+    keeps its index in the whole spectrum as its identity in the draw keys
+    (vamp_set_region_ids), so its chain is the one the single-context batch produces.
+
+    ``backend``: a ``HipContext`` on this rank's device (tests: the host implementation of the ABI).
+    ``xs / fluxes / noises / n_comp / thetas0``: per-region lists for the WHOLE spectrum, identical on
+    every rank."""
+
+    def __init__(self, backend, xs, fluxes, noises, n_comp, thetas0, seed, mode, dist=None, split_block=None, costs=None,
+                 **region_kw):
+        self.backend, self.dist = backend, dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.n_regions = len(xs)
+        W = np.asarray(thetas0[0]).shape[0]
+        if costs is None:
+            costs = [float(W) * len(x) * int(k) for x, k in zip(xs, n_comp)]
+        self.assignment = shard_regions(costs, self.world)
+        self.mine = self.assignment[self.rank]
+        if not self.mine:
+            raise ValueError("more ranks than regions")
+        pick = lambda seq: [seq[r] for r in self.mine]
+        backend.set_regions(pick(xs), pick(fluxes), pick(noises), pick(list(n_comp)), mode=mode, **region_kw)
+        backend.set_region_ids(self.mine)
+        if split_block is None:
+            from .hip_backend import default_split_block
+            split_block = default_split_block(W)
+        backend.sampler_init([np.ascontiguousarray(thetas0[r], dtype=np.float64) for r in self.mine], seed=seed,
+                             split_block=split_block)
+
+    def run(self, n_steps, thin=1, store_chain=True):
+        """This rank's regions: {global region index: dict(chain, lnprob, n_accept)} and the seconds."""
+        res = self.backend.run(n_steps, thin=thin, store_chain=store_chain)
+        one = len(self.mine) == 1
+        out = {}
+        for i, r in enumerate(self.mine):
+            out[r] = {"n_accept": res["n_accept"] if one else res["n_accept"][i]}
+            if store_chain:
+                out[r]["chain"] = res["chain"] if one else res["chain"][i]
+                out[r]["lnprob"] = res["lnprob"] if one else res["lnprob"][i]
+        return out, res["seconds"]
+
+    def gather(self, mine):
+        """Results of every rank on every rank (host side, after the run)."""
+        if self.world == 1:
+            return dict(mine)
+        box = [None] * self.world
+        self.dist.all_gather_object(box, mine)
+        out = {}
+        for part in box:
+            out.update(part)
+        return out
+
+
 class ShardedEnsemble:
     """Drive a single-region sampler whose walkers are sharded over the ranks of ``dist``.
 

@@ -160,6 +160,14 @@ class HipContext:
         self.n_pix = [len(a) for a in xs]
         self.n_comp = [int(k) for k in n_comp]
 
+    def set_region_ids(self, ids):
+        """Global identity of every region in the draw keys (see vamp_set_region_ids)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if ids.size != self.n_regions:
+            raise ValueError("one id per region is required")
+        self._check(self._lib.vamp_set_region_ids(self._h, ids.ctypes.data_as(_lib.c_int32_p)))
+        self.region_ids = [int(i) for i in ids]
+
     # -- evaluation ----------------------------------------------------------------------
     def lnprob(self, theta, region=0, return_chi2=False):
         theta = _f64(theta)

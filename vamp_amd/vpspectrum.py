@@ -274,14 +274,40 @@ class VPspectrum():
                            'centers': empty(), 'region_numbers': empty(), 'EW': np.zeros(nreg), 'std_a': empty(),
                            'std_s': empty(), 'std_c': empty(), 'cov_as': empty(), 'difficult_fit': self.difficult_fit}
         self.regions = [self._region(s, e) for s, e in self.region_pixels]
-        for r in self.regions:
-            r.n = min(r.n, 8)           # ragged batches keep to 8 lines per region (four walkers per wavefront)
-        BatchedRegionLadder(self.regions, nwalkers=self.nwalkers or 64, iterations=self.iterations, thin=self.thin,
-                            burn=self.burn, seed=self.seed or 0, verbose=self.verbose).run()
+        # the reference's retry loop (vpspectrum.py:297-348), for all regions at once: every attempt
+        # re-estimates n and runs the ladder of the regions whose best reduced chi^2 is still above
+        # the limit, with fresh draws; a region keeps the best fit it has seen
+        best = {}
+        pending = list(range(nreg))
+        ctx = None
+        for attempt in range(max(1, int(self.convergence_attempts))):
+            regs = [self.regions[i] for i in pending]
+            for r in regs:
+                r.estimate_n()
+                r.n = min(r.n, 8)       # ragged batches keep to 8 lines per region (four walkers per wavefront)
+            ladder = BatchedRegionLadder(regs, nwalkers=self.nwalkers or 64, iterations=self.iterations, thin=self.thin,
+                                         burn=self.burn, seed=(self.seed or 0) + 7727 * attempt, verbose=self.verbose, ctx=ctx)
+            ctx = ladder.ctx
+            ladder.run()
+            still = []
+            for i, region in zip(pending, regs):
+                region.set_freedom()
+                chi = region.fit.ReducedChisquared(region.flux_array, region.fit.total.value, region.noise_array, region.freedom)
+                if i not in best or chi < best[i][0]:
+                    best[i] = (chi, region.fit)
+                if not (best[i][0] < region.chi_limit):
+                    still.append(i)
+            if self.verbose:
+                print("attempt {}: {} of {} regions above the chi^2 limit".format(attempt + 1, len(still), nreg))
+            pending = still
+            if not pending:
+                break
+        if ctx is not None:
+            ctx.close()
         for j, ((start, end), region) in enumerate(zip(self.region_pixels, self.regions)):
+            region.best_chi_squared, region.fit = best[j]
+            region.n = len(region.fit.estimated_profiles)
             region.set_freedom()
-            region.best_chi_squared = region.fit.ReducedChisquared(region.flux_array, region.fit.total.value,
-                                                                   region.noise_array, region.freedom)
             self._harvest(j, start, end, np.flip(self.wavelength_array[start:end], 0), region)
         if self.out_folder is not None:
             name = os.path.basename(self.spectrum_file or "spectrum")
