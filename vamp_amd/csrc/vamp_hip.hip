@@ -710,6 +710,8 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
         const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
         // near lines: walk the set bits of the complement of the far mask (1-3 of 16 on the headline)
+        // (VAMP_SKIP_*: timing-only builds of tools/variants.py -- the phase split in profiles/)
+#ifndef VAMP_SKIP_NEAR
         for (unsigned long long near = ~farmask & ((1ull << K) - 1ull); near; near &= near - 1ull) {
             const int k = __builtin_ctzll(near);
             const LineRec ln = L.line[k];
@@ -720,11 +722,14 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
 #pragma unroll
             for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
         }
+#endif
         // flux and weights of the tile are requested here, ahead of the Clenshaw recurrence and the
         // exponentials that separate them from their use: left to itself the compiler sinks each
         // load to its use and the wavefront sits through eight L2 round trips per tile
         double fi[T], wi[T];
+#ifndef VAMP_SKIP_FFNODES
         if (nfar > 0) ff_coefficients(L, Sx, dct, lane, nfar, mid, half);
+#endif
 #if VAMP_EARLY_LOADS
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -733,14 +738,20 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
         }
         __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifndef VAMP_SKIP_CLENSHAW
         if (nfar > 0) ff_clenshaw<double, T>(Sx, xi, mid, half, tau);
+#endif
 #pragma unroll
         for (int t = 0; t < T; ++t) {
 #if !VAMP_EARLY_LOADS
             fi[t] = f[base + 64 * t + lane];
             wi[t] = wt[base + 64 * t + lane];
 #endif
+#ifdef VAMP_SKIP_EXP
+            const double m = 1.0 - tau[t];
+#else
             const double m = vamp::exp_taylor(-tau[t]);
+#endif
             const double r = (fi[t] - m) * wi[t];
             chi = fma(r, r, chi);
         }
