@@ -277,6 +277,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "VAMP_BENCH_DEVICE" in os.environ:          # rehearsal knob: several ranks on one GPU (host logic only)
+        local_rank = int(os.environ["VAMP_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
