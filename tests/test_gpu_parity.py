@@ -276,6 +276,40 @@ def test_packed_launch_classes_at_production_size(dtype):
             assert np.allclose(res["lnprob"][r][:, ok], lchain[:, ok], rtol=1e-9, atol=1e-9)
 
 
+def test_config2_shape_against_oracle(hip_ctx):
+    """BASELINE.json config 2 on its own workload: the H I Ly-alpha region [672, 716) of
+    simba_H1215.h5, 4 Voigt components, 4096 walkers, fp64 (tools/bench_c2.py times this shape).
+    lnprob of all 4096 starting walkers and five full stretch steps of the whole ensemble against
+    the oracle (numpy-vectorised replay of the counter-based draws)."""
+    from vamp_amd.physics import Wave2freq
+    g = load_golden("simba_spectra.npz")
+    s, e = g["H1215_region_pixels"][0]
+    nu = np.flip(Wave2freq(g["H1215_wavelength"][s:e]), 0)
+    flux, noise = np.flip(g["H1215_flux"][s:e], 0), np.flip(g["H1215_noise"][s:e], 0)
+    x = (nu - 0.5 * (nu[0] + nu[-1])) / ((nu[-1] - nu[0]) / (nu.size - 1))
+    assert x.size == 44
+    rng = np.random.default_rng(2)
+    K, W = 4, 4096
+    th = np.empty((W, 4 * K))
+    for k in range(K):
+        th[:, 4 * k] = rng.gamma(2.0, 1.0, W)
+        th[:, 4 * k + 1] = rng.uniform(x[0], x[-1], W)
+        th[:, 4 * k + 2] = rng.uniform(0.5, 8, W)
+        th[:, 4 * k + 3] = rng.uniform(2, 15, W)
+    reg = vo.Region(x=x, flux=flux, noise=noise, n_comp=K, mode=vo.MODE_VOIGT4)
+    fn = lambda q: vo.log_prob_batch_fast(reg, q)
+    want = fn(th)
+    hip_ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
+    got = hip_ctx.lnprob(th)
+    assert np.isfinite(want).all() and np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) <= 1e-9
+    hip_ctx.sampler_init(th, seed=5, split_block=1024)
+    res = hip_ctx.run(5)
+    chain, lchain, nacc = vo.run_sampler_batch(fn, th, want, 5, seed=5, block=1024)
+    ok = np.all(np.abs(res["chain"] - chain) <= 1e-10 * np.abs(chain) + 1e-12, axis=(0, 2))
+    assert (~ok).sum() <= 1 and np.abs(res["n_accept"] - nacc).sum() <= 1      # 20 480 decisions: a rounding-level margin may flip one
+    assert 0.02 < nacc.mean() / 5 < 0.9
+
+
 def test_sampler_sd_mode_and_acceptance(hip_ctx):
     """Reference-form likelihood (free sd, vpfits.py:39): stored lnprob equals a fresh evaluation
     of the final positions, and the acceptance fraction is sane."""

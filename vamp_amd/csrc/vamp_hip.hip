@@ -44,6 +44,9 @@
 #ifndef VAMP_EARLY_LOADS
 #define VAMP_EARLY_LOADS 1
 #endif
+#ifndef VAMP_X_PREFETCH
+#define VAMP_X_PREFETCH 0
+#endif
 #ifndef VAMP_EARLY_LNP
 #define VAMP_EARLY_LNP 1
 #endif
@@ -697,8 +700,35 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
     const double my_c = L.line[kk].c;
     const double my_w8 = sqrt(fmax(vamp::R2_CORE - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
     const double my_w25 = sqrt(fmax(vamp::R2_M3 - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
+#if VAMP_X_PREFETCH
+    // the abscissae of a tile are requested one tile ahead: they head every dependency chain of the
+    // tile (classification, near lines, Clenshaw), and an L2 round trip at the top of each of the
+    // 16 iterations is paid by all the wavefronts of a workgroup together
+    double xn[T], xn_lo = 0.0, xn_hi = 0.0;
+    if (base0 < base1) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) xn[t] = x[base0 + 64 * t + lane];
+        xn_lo = x[base0];
+        xn_hi = x[base0 + 64 * T - 1];
+    }
+#endif
     for (int base = base0; base < base1; base += stride) {
         double xi[T], tau[T];
+#if VAMP_X_PREFETCH
+        const double x_lo = xn_lo, x_hi = xn_hi;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            xi[t] = xn[t];
+            tau[t] = 0.0;
+        }
+        {
+            const int nb = base + stride < base1 ? base + stride : base;     // the last tile re-reads itself
+#pragma unroll
+            for (int t = 0; t < T; ++t) xn[t] = x[nb + 64 * t + lane];
+            xn_lo = x[nb];
+            xn_hi = x[nb + 64 * T - 1];
+        }
+#else
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             xi[t] = x[base + 64 * t + lane];
@@ -706,6 +736,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
         }
         // tile geometry (wave-uniform)
         const double x_lo = x[base], x_hi = x[base + 64 * T - 1];
+#endif
         const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * fabs(x_hi - x_lo);
         const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
@@ -1291,9 +1322,15 @@ __global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(Sampl
     }
     const RegionDev R = S.regions[region];
     WalkerLds<PK::KCAP>& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
+#ifdef VAMP_ROWS_CACHED    // timing-only builds: every row read hits a 64-row window (no HBM latency)
+    double* Xs = S.X + R.theta_off + (ws & 63) * R.D;
+    const double* Xc = S.X + R.theta_off + (wc & 63) * R.D;
+    const long long wg = R.walker_off + (ws & 63);
+#else
     double* Xs = S.X + R.theta_off + ws * R.D;
     const double* Xc = S.X + R.theta_off + wc * R.D;
     const long long wg = R.walker_off + ws;
+#endif
     // the mover's current lnprob is requested together with the two rows: three random reads of a
     // state far larger than L2, one exposed round trip instead of two (it is needed only for the
     // accept test, and left there its miss is paid in full by the one or two waves a SIMD holds)
@@ -1915,6 +1952,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
     if (mode != VAMP_GAUSS3 && mode != VAMP_VOIGT4 && mode != VAMP_NBZ3) return fail(VAMP_ERR_ARG, "vamp_set_regions: bad mode");
     if (mode == VAMP_NBZ3 && !nbz) return fail(VAMP_ERR_ARG, "vamp_set_regions: VAMP_NBZ3 needs nbz");
     if (pix_off[0] != 0) return fail(VAMP_ERR_ARG, "vamp_set_regions: pix_off[0] must be 0");
+    if (n_regions > 65535) return fail(VAMP_ERR_ARG, "vamp_set_regions: at most 65535 regions per context (one grid row per region)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_sampler(c);
