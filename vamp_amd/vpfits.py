@@ -419,43 +419,41 @@ class VPfit():
 
     def plot(self, wavelength_array, flux_array, clouds=None, n=1, onesigmaerror=0.02,
              start_pix=None, end_pix=None, filename=None):
-        """Residuals / components / total-fit figure (vpfits.py:134-199)."""
+        """Diagnostic figure with the reference's signature (vpfits.py:134): residuals in units of
+        ``onesigmaerror``, the fitted components, the total model.  Plotting is outside the hot
+        path; this is a minimal stand-in so that callers of ``plot`` keep working."""
         import matplotlib
         if filename:
             matplotlib.use("Agg")
-        import matplotlib.pyplot as plt
-        if not start_pix:
-            start_pix = 0
-        if not end_pix:
-            end_pix = len(wavelength_array)
-        f, (ax1, ax2, ax3) = plt.subplots(3, sharex=True, sharey=False, figsize=(10, 10))
-        ax1.plot(wavelength_array, (flux_array - self.total.value) / onesigmaerror)
-        for lvl, ls in ((1, '-'), (-1, '-'), (3, '--'), (-3, '--')):
-            ax1.hlines(lvl, wavelength_array[0], wavelength_array[-1], color='red', linestyles=ls)
-        ax2.plot(wavelength_array, flux_array, color='black', linewidth=1.0)
-        if clouds is not None:
-            for c in range(len(clouds)):
-                ax2.plot(wavelength_array, Tau2flux(clouds.iloc[c]['tau'][start_pix:end_pix]), color="red",
-                         label="Actual" if c == 0 else None, lw=1.5)
-        for c in range(n):
-            ax2.plot(wavelength_array, Tau2flux(self.estimated_profiles[c].value), color="green",
-                     label="Fit" if c == 0 else None)
-        ax2.legend()
-        ax3.plot(wavelength_array, flux_array, label="Measured")
-        ax3.plot(wavelength_array, self.total.value, color='green', label="Fit", linewidth=2.0)
-        ax3.legend()
-        f.subplots_adjust(hspace=0)
-        if hasattr(self, 'fit_time'):
-            ax1.set_title("Fit time: " + self.fit_time)
-        ax1.set_ylabel("Residuals")
-        ax2.set_ylabel("Normalised Flux")
-        ax3.set_ylabel("Normalised Flux")
-        ax3.set_xlabel(r"$ \lambda (\AA)$")
-        if filename:
-            plt.savefig(filename)
-            plt.close(f)
-        else:
-            plt.show()
+        from matplotlib import pyplot
+        lam = np.asarray(wavelength_array)
+        lo = start_pix or 0
+        hi = end_pix or lam.size
+        fig, panels = pyplot.subplots(3, 1, sharex=True, figsize=(10, 10), gridspec_kw={"hspace": 0})
+        resid, comps, total = panels
+        resid.plot(lam, (np.asarray(flux_array) - self.total.value) / onesigmaerror)
+        for level in (-3, -1, 1, 3):
+            resid.axhline(level, color="red", linestyle="-" if abs(level) == 1 else "--")
+        comps.plot(lam, flux_array, color="black", linewidth=1.0)
+        truth = [] if clouds is None else [np.asarray(clouds.iloc[i]["tau"])[lo:hi] for i in range(len(clouds))]
+        fitted = [self.estimated_profiles[k].value for k in range(n)]
+        for taus, colour, label, width in ((truth, "red", "Actual", 1.5), (fitted, "green", "Fit", None)):
+            for i, tau in enumerate(taus):
+                comps.plot(lam, Tau2flux(tau), color=colour, label=label if i == 0 else None, lw=width)
+        total.plot(lam, flux_array, label="Measured")
+        total.plot(lam, self.total.value, color="green", linewidth=2.0, label="Fit")
+        for ax, ylabel in zip(panels, ("Residuals", "Normalised Flux", "Normalised Flux")):
+            ax.set_ylabel(ylabel)
+        comps.legend()
+        total.legend()
+        total.set_xlabel(r"$ \lambda (\AA)$")
+        if getattr(self, "fit_time", None):
+            resid.set_title("Fit time: " + self.fit_time)
+        if not filename:
+            pyplot.show()
+            return
+        fig.savefig(filename)
+        pyplot.close(fig)
 
     # copy.copy(fit) is used by VPregion (vpregion.py:65,72): share the device context
     def __copy__(self):
