@@ -143,6 +143,11 @@ int vamp_map_all(vamp_ctx* ctx, const double* theta0, const uint8_t* active, int
  * .value the callers read (vpspectrum.py:335,352-363).  Either output may be NULL. */
 int vamp_model(vamp_ctx* ctx, int region, const double* theta1, double* tau_comp,
                double* flux_model);
+/* The same for EVERY region in one launch (the fits of all regions of a spectrum end together:
+ * vpspectrum.py:351-365 reads their values one after the other): theta = the regions' D_r-vectors
+ * one after the other, tau_comp = their [K_r, P_r] blocks one after the other, flux_model laid out
+ * like the pixels.  Either output may be NULL. */
+int vamp_model_all(vamp_ctx* ctx, const double* theta, double* tau_comp, double* flux_model);
 
 /* The per-line records the kernels stage in LDS for one parameter vector, rec[K*5] =
  * {centroid, x-scale, damping y, tau scale, pole factor} per component, and the log-prior: test

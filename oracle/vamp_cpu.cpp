@@ -527,6 +527,20 @@ int vamp_model(vamp_ctx* c, int region, const double* theta1, double* tau_comp, 
     return VAMP_OK;
 }
 
+int vamp_model_all(vamp_ctx* c, const double* theta, double* tau_comp, double* flux_model) {
+    if (!c || !theta) return fail(VAMP_ERR_ARG, "vamp_model_all: NULL argument");
+    if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_model_all: call vamp_set_regions first");
+    long long tau_off = 0;
+    for (int r = 0; r < c->n_regions; ++r) {
+        const Region& R = c->R[r];
+        int rc = vamp_model(c, r, theta + R.d_before, tau_comp ? tau_comp + tau_off : nullptr,
+                            flux_model ? flux_model + R.pix_off : nullptr);
+        if (rc) return rc;
+        tau_off += (long long)R.K * R.P;
+    }
+    return VAMP_OK;
+}
+
 int vamp_line_records(vamp_ctx* c, int region, const double* theta1, double* rec, double* lnprior) {
     if (!c || !theta1 || !rec || !lnprior) return fail(VAMP_ERR_ARG, "vamp_line_records: NULL argument");
     if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_line_records: call vamp_set_regions first");

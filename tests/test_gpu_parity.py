@@ -126,6 +126,29 @@ def test_multi_region_batch_matches_single(hip_ctx):
         assert np.max(np.abs(got[fin] - want[fin]) / np.maximum(1, np.abs(want[fin]))) <= 1e-9
 
 
+def test_model_all_equals_model_region_by_region(hip_ctx):
+    """vamp_model_all (component optical depths and model flux of EVERY region from one launch, ragged
+    outputs) == vamp_model per region, and the oracle's component_taus / model_flux."""
+    g = load_golden("lnprob_cases.npz")
+    names = [f"H1215_r{i}_K4_m1_sd0" for i in range(3)] + ["H1215_r0_K1_m1_sd0"]
+    xs, fs, ns = [g[n + "_x"] for n in names], [g[n + "_flux"] for n in names], [g[n + "_noise"] for n in names]
+    ks = [4, 4, 4, 1]
+    hip_ctx.set_regions(xs, fs, ns, ks, mode=vo.MODE_VOIGT4)
+    thetas = []
+    for n_, k in zip(names, ks):
+        th, lnp = g[n_ + "_theta"], g[n_ + "_lnprob"]
+        thetas.append(th[np.nanargmax(np.where(np.isfinite(lnp), lnp, -np.inf))])
+    taus, fluxes = hip_ctx.model_all(thetas)
+    for r in range(4):
+        t1, f1 = hip_ctx.model(thetas[r], region=r)
+        assert np.array_equal(taus[r], t1) and np.array_equal(fluxes[r], f1)
+        reg = vo.Region(x=xs[r], flux=fs[r], noise=ns[r], n_comp=ks[r], mode=vo.MODE_VOIGT4)
+        want = vo.component_taus(reg, thetas[r])
+        big = want > 1e-290
+        assert np.max(np.abs(taus[r][big] - want[big]) / want[big]) <= 1e-12
+        assert np.allclose(fluxes[r], vo.model_flux(reg, thetas[r]), rtol=1e-12, atol=1e-300)
+
+
 def test_stretch_injected_draws_parity(hip_ctx):
     g = load_golden("stretch_traj.npz")
     hip_ctx.set_regions(g["x"], g["flux"], g["noise"], 1, mode=vo.MODE_VOIGT4)

@@ -38,6 +38,7 @@ SIGNATURES = {
     "vamp_map_all": (C.c_int, [C.c_void_p, c_double_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double, c_double_p,
                      c_double_p, c_double_p, c_int64_p]),
     "vamp_model": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "vamp_model_all": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "vamp_line_records": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "vamp_wofz_re": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
     "vamp_sampler_init": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_uint64, C.c_double, C.c_int32]),

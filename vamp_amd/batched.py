@@ -25,11 +25,25 @@ from .vpfits import VPfit, _EnsembleMCMC, _MAP
 MAX_COMPONENTS = 16      # VAMP_MAX_COMPONENTS of include/vamp_hip.h
 
 
+class _DeferredModel:
+    """Stands in for the context while a batched fit is set up: the start point's component / total
+    values are never read (the ensemble run replaces them), so no per-region ``vamp_model`` launch."""
+
+    def __init__(self, n_pix):
+        self.n_pix = n_pix
+
+    def model(self, theta, region=0):
+        return None, None
+
+
 def _bound_fit(ctx, region_index, nu, flux, n, voigt, nwalkers, seed):
     fit = VPfit(seed=seed)
     fit.nwalkers = nwalkers
-    fit._ctx, fit._region, fit._shared_ctx = ctx, region_index, True
+    fit._region, fit._shared_ctx = region_index, True
+    fit._ctx = _DeferredModel(flux.size)
+    fit._set_values_deferred = True
     fit.initialise_model(nu, flux, n, voigt=voigt)
+    fit._ctx = ctx
     return fit
 
 
@@ -58,7 +72,9 @@ def find_bic_batched(ctx, regions, ns, voigt=False, nwalkers=64, iterations=3000
                for r in range(R)]
         for f in cur:
             f.map, f.mcmc = _MAP(f), _EnsembleMCMC(f)
-        X0 = [f._initial_walkers() for f in cur]
+        drawn = [f._draw_walkers() for f in cur]
+        lnp0 = ctx.lnprob_all([d[0] for d in drawn])              # one launch instead of one per region
+        X0 = [f._finish_walkers(d[0], d[1], lnp0[r]) for r, (f, d) in enumerate(zip(cur, drawn))]
         ctx.sampler_init(X0, seed=(seed * 2654435761 + rep) & (2 ** 64 - 1), a=2.0, split_block=hb.default_split_block(W))
         if burn > 0:
             ctx.run(burn, store_chain=False)
@@ -66,12 +82,19 @@ def find_bic_batched(ctx, regions, ns, voigt=False, nwalkers=64, iterations=3000
         chains = res["chain"] if R > 1 else [res["chain"]]
         lnps = res["lnprob"] if R > 1 else [res["lnprob"]]
         naccs = res["n_accept"] if R > 1 else [res["n_accept"]]
+        # every kept sample of every region scored in ONE launch (DIC / BPIC), the mean points in another
+        flats = [chains[r].reshape(-1, cur[r]._ndim) for r in range(R)]
+        lnp_s, ss_s = ctx.lnprob_all(flats, return_chi2=True)
+        lnp_m, ss_m = ctx.lnprob_all([fl.mean(0)[None, :] for fl in flats], return_chi2=True)
         for r, f in enumerate(cur):
-            f._ingest_chain(chains[r], lnps[r], naccs[r], burn + keep, keep, res["seconds"])
-        # the MAP polish of every region together: one launch per Nelder-Mead iteration
+            f._ingest_chain(chains[r], lnps[r], naccs[r], burn + keep, keep, res["seconds"],
+                            scored=((lnp_s[r], ss_s[r]), (lnp_m[r, 0], ss_m[r, 0])), set_values=False)
+        # the MAP polish of every region together: one launch per Nelder-Mead iteration; then the
+        # component and total values of all optima from one launch (vamp_model_all)
         best, lnp_best, ssum_best, _ = ctx.map_all([f._map_start() for f in cur], iterlim=iterations, tol=1e-3)
+        taus, fluxes = ctx.model_all(best)
         for r, f in enumerate(cur):
-            f._map_finish(best[r], lnp_best[r], ssum_best[r], f.map)
+            f._map_finish(best[r], lnp_best[r], ssum_best[r], f.map, model=(taus[r], fluxes[r]))
             nu, flux, noise = regions[r]
             freedom = freedoms[r] if freedoms is not None else flux.size - 3 * ns[r]
             bics[r].append(f.map.BIC)

@@ -83,6 +83,7 @@ struct RegionDev {
     long long theta_off;   // doubles: start of this region's [W, D] block in the sampler state
     long long walker_off;  // first global walker id of this region in the sampler state
     long long d_before;    // sum of D over the preceding regions (vamp_lnprob_all: block r starts at W * d_before)
+    long long tau_off;     // sum of K * P over the preceding regions (vamp_model_all: this region's tau_comp block)
     int P, K, mode, D;     // D = q*K (+1 if sample_sd)
     int sample_sd, q, rng_id, pad1;   // rng_id: the region's identity in the draw keys (default: its index)
     double c_lo, c_hi;     // centroid prior (vpfits.py:250,293)
@@ -1089,14 +1090,24 @@ __global__ __launch_bounds__(PK::THREADS, 3) void k_lnprob(const RegionDev* __re
     }
 }
 
-// tau_k[P] and flux[P] for one parameter vector (one thread per pixel)
+// tau_k[P] and flux[P] for one parameter vector (one thread per pixel).  region < 0: every region in
+// one launch (blockIdx.y = region): theta holds the regions' D_r-vectors one after the other,
+// tau_comp the [K_r, P_r] blocks one after the other, flux_model is laid out like the pixels.
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_model(const RegionDev* __restrict__ regions, int region, PixPtrs px,
                                                  const double* __restrict__ theta, double* __restrict__ tau_comp,
                                                  double* __restrict__ flux_model) {
     __shared__ WaveLds lds[WAVES_PER_BLOCK];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool all = region < 0;
+    if (all) region = blockIdx.y;
     const RegionDev R = regions[region];
+    if ((int)(blockIdx.x * BLOCK) >= R.P) return;          // (uniform per block: regions differ in length)
+    if (all) {
+        theta += R.d_before;
+        if (tau_comp) tau_comp += R.tau_off;
+        if (flux_model) flux_model += R.pix_off;
+    }
     WaveLds& L = lds[wave];
     for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[d];
     __builtin_amdgcn_wave_barrier();
@@ -1974,6 +1985,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         d.rng_id = r;
         d.D = q * d.K + d.sample_sd;
         d.d_before = r ? R[r - 1].d_before + R[r - 1].D : 0;
+        d.tau_off = r ? R[r - 1].tau_off + (long long)R[r - 1].K * R[r - 1].P : 0;
         const double* xr = x + pix_off[r];
         if (bounds) {
             d.c_lo = bounds[4 * r + 0];
@@ -2217,6 +2229,29 @@ int vamp_model(vamp_ctx* c, int region, const double* theta1, double* tau_comp, 
     HIP_TRY(hipGetLastError());
     if (tau_comp) HIP_TRY(hipMemcpyAsync(tau_comp, tau_d, (size_t)R.K * R.P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (flux_model) HIP_TRY(hipMemcpyAsync(flux_model, fl_d, (size_t)R.P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VAMP_OK;
+}
+
+int vamp_model_all(vamp_ctx* c, const double* theta, double* tau_comp, double* flux_model) {
+    if (!c || !theta) return fail(VAMP_ERR_ARG, "vamp_model_all: NULL argument");
+    if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_model_all: call vamp_set_regions first");
+    HIP_TRY(hipSetDevice(c->device));
+    const RegionDev& last = c->regions_h.back();
+    const size_t nth = (size_t)(last.d_before + last.D), ntau = (size_t)(last.tau_off + (long long)last.K * last.P);
+    int pmax = 0;
+    for (const RegionDev& R : c->regions_h) pmax = std::max(pmax, R.P);
+    DevBuf th_b, tau_b, fl_b;
+    HIP_TRY(hipMalloc(&th_b.p, nth * sizeof(double)));
+    if (tau_comp) HIP_TRY(hipMalloc(&tau_b.p, ntau * sizeof(double)));
+    if (flux_model) HIP_TRY(hipMalloc(&fl_b.p, (size_t)c->n_pix * sizeof(double)));
+    double *th_d = th_b.as<double>(), *tau_d = tau_b.as<double>(), *fl_d = fl_b.as<double>();
+    HIP_TRY(hipMemcpyAsync(th_d, theta, nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((unsigned)((pmax + BLOCK - 1) / BLOCK), (unsigned)c->n_regions);
+    VAMP_FOR_MODE(c->mode, hipLaunchKernelGGL((k_model<M>), grid, dim3(BLOCK), 0, c->stream, c->regions_d, -1, c->pix(), th_d, tau_d, fl_d));
+    HIP_TRY(hipGetLastError());
+    if (tau_comp) HIP_TRY(hipMemcpyAsync(tau_comp, tau_d, ntau * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (flux_model) HIP_TRY(hipMemcpyAsync(flux_model, fl_d, (size_t)c->n_pix * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VAMP_OK;
 }

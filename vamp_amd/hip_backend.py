@@ -231,6 +231,21 @@ class HipContext:
         self._check(self._lib.vamp_model(self._h, region, _dp(theta1), _dp(tau), _dp(flux)))
         return tau, flux
 
+    def model_all(self, thetas):
+        """(tau_comp, flux) of every region from ONE launch: lists of [K_r, P_r] and [P_r] arrays for
+        one D_r-vector per region."""
+        vecs = [_f64(np.ravel(t)) for t in thetas]
+        if len(vecs) != self.n_regions or any(v.size != d for v, d in zip(vecs, self.ndims)):
+            raise ValueError("one parameter vector of the region's dimension per region is required")
+        flat = np.concatenate(vecs)
+        sizes = [k * p for k, p in zip(self.n_comp, self.n_pix)]
+        tau = np.empty(sum(sizes))
+        flux = np.empty(sum(self.n_pix))
+        self._check(self._lib.vamp_model_all(self._h, _dp(flat), _dp(tau), _dp(flux)))
+        to, po = np.concatenate([[0], np.cumsum(sizes)]), np.concatenate([[0], np.cumsum(self.n_pix)])
+        return ([tau[to[r]:to[r + 1]].reshape(self.n_comp[r], self.n_pix[r]) for r in range(self.n_regions)],
+                [flux[po[r]:po[r + 1]] for r in range(self.n_regions)])
+
     def line_records(self, theta1, region=0):
         """(rec[K,5] = centroid, x-scale, y, tau scale, pole factor;  log-prior) as staged on device"""
         theta1 = _f64(theta1).ravel()

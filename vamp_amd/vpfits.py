@@ -251,8 +251,10 @@ class VPfit():
     def _to_caller(self, theta_dev):
         return theta_dev * self._scale + self._shift
 
-    def _set_values(self, theta_dev):
-        """Put one parameter vector on the nodes: .value of every variable, component and total."""
+    def _set_values(self, theta_dev, model=None):
+        """Put one parameter vector on the nodes: .value of every variable, component and total.
+        ``model`` = (tau[K, P], flux[P]) when the caller already has them (batched fits evaluate
+        the models of all regions in one launch), else one ``vamp_model`` call."""
         theta_dev = np.asarray(theta_dev, dtype=np.float64)
         self._theta_dev = theta_dev.copy()
         vals = self._to_caller(theta_dev)
@@ -261,7 +263,9 @@ class VPfit():
                 self._sd_node.value = float(v)
             else:
                 self.estimated_variables[k][key].value = float(v)
-        tau, flux = self._ctx.model(theta_dev, region=self._region)
+        tau, flux = model if model is not None else self._ctx.model(theta_dev, region=self._region)
+        if tau is None:          # a batched fit being set up: values follow from the first batched evaluation
+            return
         for k in range(self._n):
             self.estimated_profiles[k].value = tau[k].copy()
         self.total.value = flux
@@ -294,9 +298,9 @@ class VPfit():
             return self._chain_dev[i[0], i[1]]
         return self._theta_dev
 
-    def _map_finish(self, best, lnp_best, ssum_best, mp):
+    def _map_finish(self, best, lnp_best, ssum_best, mp, model=None):
         """Adopt the optimum and fill the MAP object (PyMC 2.3 definitions, see _MAP)."""
-        self._set_values(best)
+        self._set_values(best, model=model)
         mp.logp_at_max = float(lnp_best)
         mp.lnL = float(np.ravel(self._loglike_from_sum(best, lnp_best, ssum_best))[0])
         k, n = self._ndim, self._flux.size
@@ -330,9 +334,9 @@ class VPfit():
         self.fit_time = str(datetime.datetime.now() - starttime)
         print("\nTook:", self.fit_time, " to finish.")
 
-    def _initial_walkers(self):
-        """[W, D] start of the ensemble: a ball around the current point (the MAP, when
-        map_estimate ran first) widened with prior draws so that a poor start cannot trap it."""
+    def _draw_walkers(self):
+        """[W, D] start of the ensemble before the prior check: a ball around the current point (the
+        MAP, when map_estimate ran first) and one prior draw per walker to fall back on."""
         W = int(self.nwalkers)
         W = max(W, 2 * self._ndim + 2)
         W += W % 2
@@ -341,11 +345,19 @@ class VPfit():
         span = np.abs(self._draw_prior(rng, W) - centre)
         X0 = centre + 1e-2 * span * rng.standard_normal((W, self._ndim))
         prior = self._draw_prior(rng, W)
-        lnp = self._ctx.lnprob(X0, region=self._region)
+        return X0, prior
+
+    def _finish_walkers(self, X0, prior, lnp):
+        """walkers of the ball that fall outside the prior are replaced by their prior draw, so that
+        a poor start cannot trap the ensemble; walker 0 is the current point itself"""
         bad = ~np.isfinite(lnp)
         X0[bad] = prior[bad]
-        X0[0] = centre
+        X0[0] = self._theta_dev
         return X0
+
+    def _initial_walkers(self):
+        X0, prior = self._draw_walkers()
+        return self._finish_walkers(X0, prior, self._ctx.lnprob(X0, region=self._region))
 
     def _run_sampler(self, iterations, burn, thin):
         X0 = self._initial_walkers()
@@ -358,12 +370,14 @@ class VPfit():
         res = self._ctx.run(keep, thin=thin)
         self._ingest_chain(res["chain"], res["lnprob"], res["n_accept"], burn + keep, keep, res["seconds"])
 
-    def _ingest_chain(self, chain, lnpc, n_accept, steps, keep, seconds):
+    def _ingest_chain(self, chain, lnpc, n_accept, steps, keep, seconds, scored=None, set_values=True):
         """chain [n_keep, W, D] / lnprob [n_keep, W] of THIS fit's region -> traces, acceptance,
-        DIC / BPIC, node values."""
+        DIC / BPIC, node values.  ``scored`` = (lnprob, sum) of every kept sample and of the mean
+        point when the caller scored them already (batched fits: all regions in one launch)."""
         W = chain.shape[1]
         self._chain_dev, self._lnp_chain = chain, lnpc
-        flat = self._to_caller(chain.reshape(-1, self._ndim))
+        flat_dev = chain.reshape(-1, self._ndim)
+        flat = self._to_caller(flat_dev)
         mc_ = self.mcmc
         mc_._traces = {nm: flat[:, j].copy() for j, nm in enumerate(self._names)}
         if self._voigt:      # the reference's callers ask for est_sigma_k in Voigt mode too (vpspectrum.py:400)
@@ -372,15 +386,22 @@ class VPfit():
         mc_.acceptance_fraction = float(np.mean(n_accept)) / max(1, steps)
         mc_.walker_steps_per_second = W * keep / seconds if seconds > 0 else float("nan")
         # information criteria from the chain (every kept sample scored on the device)
-        ll = self._loglike(chain.reshape(-1, self._ndim))
+        mean_theta = flat_dev.mean(0)
+        if scored is None:
+            ll = self._loglike(flat_dev)
+            ll_mean = self._loglike(mean_theta)[0]
+        else:
+            (lnp_s, ss_s), (lnp_m, ss_m) = scored
+            ll = self._loglike_from_sum(flat_dev, lnp_s, ss_s)
+            ll_mean = self._loglike_from_sum(mean_theta, np.atleast_1d(lnp_m), np.atleast_1d(ss_m))[0]
         dev_mean = float(np.mean(-2.0 * ll[np.isfinite(ll)]))
-        mean_theta = chain.reshape(-1, self._ndim).mean(0)
-        dev_at_mean = float(-2.0 * self._loglike(mean_theta)[0])
+        dev_at_mean = float(-2.0 * ll_mean)
         mc_.DIC = 2 * dev_mean - dev_at_mean
         mc_.BPIC = 3 * dev_mean - 2 * dev_at_mean
         # leave the nodes at the best posterior sample (PyMC leaves them at the last sample)
-        i = np.unravel_index(np.argmax(lnpc), lnpc.shape)
-        self._set_values(chain[i[0], i[1]])
+        if set_values:
+            i = np.unravel_index(np.argmax(lnpc), lnpc.shape)
+            self._set_values(chain[i[0], i[1]])
 
     def find_bic(self, frequency_array, flux_array, n, noise_array, freedom, voigt=False,
                  iterations=3000, thin=15, burn=300, thorough=False):
