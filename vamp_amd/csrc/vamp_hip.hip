@@ -47,6 +47,9 @@
 #ifndef VAMP_X_PREFETCH
 #define VAMP_X_PREFETCH 0
 #endif
+#ifndef VAMP_MIN_WAVES
+#define VAMP_MIN_WAVES 3
+#endif
 #ifndef VAMP_EARLY_LNP
 #define VAMP_EARLY_LNP 1
 #endif
@@ -130,6 +133,9 @@ struct Pack {
     static constexpr int WPB = WPB_;        // wavefronts per workgroup
     static constexpr int THREADS = 64 * WPB_;
     static constexpr int WALKERS_PER_BLOCK = SPLIT_ ? 1 : WPB_ * SUBS;
+    // wavefronts per SIMD the register allocation aims for: 3 (<= 168 VGPRs) everywhere except the
+    // blend shape, whose 22 KB of LDS per single-wave workgroup allow fewer than 2 anyway
+    static constexpr int MIN_WAVES = (SPLIT_ && TABS_ && !FF_) ? 2 : VAMP_MIN_WAVES;
     static_assert(!SPLIT_ || (LPW_ == 64 && (WPB_ == PARTS || !FF_) && WPB_ <= PARTS),
                   "a split workgroup is PARTS wavefronts on one walker (tile classes), or up to PARTS wavefronts without far field (contiguous shares)");
 };
@@ -1051,7 +1057,7 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::
 // kernels
 // ---------------------------------------------------------------------------------------
 template <bool F32, int MODE, class PK>
-__global__ __launch_bounds__(PK::THREADS, 3) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
+__global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
                                                   long long W, const double* __restrict__ theta,
                                                   double* __restrict__ lnprob, double* __restrict__ chi2,
                                                   const int* __restrict__ region_list) {
@@ -1284,12 +1290,9 @@ __global__ __launch_bounds__(256) void k_draws(SamplerDev S, unsigned step, int 
 //   (deterministic-parity hook); DRAW_PRE: read from the arrays k_draws filled for this launch.
 // 3 waves per SIMD (<= 168 VGPRs): the far-field path is latency-bound in places (LDS round trips);
 // measured 6.94 -> 6.49 ms against the allocator's unconstrained 182 VGPRs / 2 waves
-#ifndef VAMP_MIN_WAVES
-#define VAMP_MIN_WAVES 3
-#endif
 constexpr int DRAW_INLINE = 0, DRAW_HOST = 1, DRAW_PRE = 2;
 template <bool F32, int DRAWS, int MODE, class PK>
-__global__ __launch_bounds__(PK::THREADS, VAMP_MIN_WAVES) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
+__global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
                                                      long long ext_n, const int* __restrict__ ext_active,
                                                      const int* __restrict__ ext_partner, const double* __restrict__ ext_z,
                                                      const double* __restrict__ ext_logu, const double* __restrict__ ext_logz) {
