@@ -438,3 +438,52 @@ def test_default_stream_orders_with_torch_and_run_dev_records_on_device():
         torch.cuda.synchronize()
         got = np.stack([s.cpu().numpy().reshape(X0.shape) for s in snaps])
         assert np.array_equal(got, ref["chain"])
+
+
+def _fake_rccl_worker(rank, world, port, out_dir, parts):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      VAMP_RCCL_LIB=os.path.join(ROOT, "tests", "host", "librccl_fake.so"))
+    import torch.distributed as dist
+    import vamp_amd
+    from vamp_amd.ensemble import ShardedEnsemble
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    region, X0 = _big_case(256)
+    ctx = vamp_amd.HipContext(device=0)
+    ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+    ens = ShardedEnsemble(ctx, X0, seed=77, split_block=16, dist=dist, exchange="rccl", parts=parts)
+    assert ens.exchange == "rccl" and ens.own_count == X0.shape[0] // world
+    ens.step(2)                                   # half-step by half-step ...
+    ens.run_dev(4)                                # ... and the whole loop in one library call
+    X, lnp, nacc = ens.gather_state()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "fake.npz"), X=X, lnp=lnp, nacc=nacc)
+    dist.barrier()
+    ctx.comm_destroy()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,parts", [(2, 1), (2, 2), (4, 2)])
+def test_in_library_exchange_several_ranks_on_one_gpu(world, parts, tmp_path):
+    """The production multi-GPU path end to end at world > 1 on the one-GPU box: vamp_comm_unique_id
+    -> id over gloo -> vamp_comm_init_rank -> set_shard_parts -> pack in the half-step kernel ->
+    all-gather -> k_scatter_rows, driven by vamp_sampler_half_step and vamp_sampler_run_dev.  The wire
+    is a stand-in for RCCL (tests/host/rccl_fake.cpp, host shared memory; RCCL refuses two ranks on
+    one device); everything else is the code the 8-GPU run executes.  Same chain as one rank."""
+    import torch.multiprocessing as mp
+    import vamp_amd
+    if not os.path.exists(os.path.join(ROOT, "tests", "host", "librccl_fake.so")):
+        import __graft_entry__ as ge
+        ge.build()
+    mp.spawn(_fake_rccl_worker, args=(world, _free_port(), str(tmp_path), parts), nprocs=world, join=True)
+    r = np.load(os.path.join(str(tmp_path), "fake.npz"))
+    region, X0 = _big_case(256)
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+        ctx.sampler_init(X0, seed=77, split_block=16)
+        ctx.run(6, store_chain=False)
+        X1, lnp1, nacc1, _ = ctx.get_state()
+    assert np.array_equal(r["X"], X1) and np.array_equal(r["lnp"], lnp1) and np.array_equal(r["nacc"], nacc1)

@@ -1765,10 +1765,16 @@ int rccl_api(RcclApi** out) {
     if (!tried) {
         tried = true;
         void* h = nullptr;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (h) break;
-        }
+        // VAMP_RCCL_LIB: a library with the five NCCL entry points used here, tried first.  The GPU tests
+        // point it at a stand-in that moves the bytes through host shared memory (tests/host/rccl_fake.cpp),
+        // which lets two ranks share the one GPU of a test box -- RCCL itself refuses that -- and runs the
+        // whole in-library exchange path at world > 1.
+        if (const char* over = getenv("VAMP_RCCL_LIB")) h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!h)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h) break;
+            }
         if (h) {
             api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
             api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
