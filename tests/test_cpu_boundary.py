@@ -52,7 +52,7 @@ def test_host_library_exports_the_whole_header(cpu_lib):
 @pytest.mark.parametrize("fn", [gp.test_device_wofz_matches_scipy_and_mpmath, gp.test_lnprob_matches_golden,
                                 gp.test_line_records_and_prior_match_oracle, gp.test_lnprob_include_norm_and_bounds,
                                 gp.test_multi_region_batch_matches_single, gp.test_model_all_equals_model_region_by_region,
-                                gp.test_stretch_injected_draws_parity,
+                                gp.test_stretch_injected_draws_parity, gp.test_smallest_shapes,
                                 gp.test_sampler_resume_and_thin, gp.test_sampler_multi_region_matches_oracle,
                                 gp.test_sampler_sd_mode_and_acceptance, gp.test_map_all_follows_scipy_fmin],
                          ids=lambda f: f.__name__)

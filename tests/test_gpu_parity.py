@@ -359,6 +359,40 @@ def test_sampler_sd_mode_and_acceptance(hip_ctx):
     assert lnp.mean() > hip_ctx.lnprob(X0).mean()          # the ensemble climbed
 
 
+def test_smallest_shapes(hip_ctx):
+    """Edges of the shape space: a 2-pixel region (the minimum vamp_set_regions accepts), the smallest
+    ensemble (W = 2, one mover per colour), a sampler asked for zero steps, thinning that keeps
+    nothing, and 16 components on a 3-pixel region -- all against the oracle."""
+    rng = np.random.default_rng(99)
+    x = np.array([-0.5, 0.5])
+    f, n = np.array([0.7, 0.8]), np.array([0.05, 0.05])
+    hip_ctx.set_regions(x, f, n, 1, mode=vo.MODE_VOIGT4)
+    reg = vo.Region(x=x, flux=f, noise=n, n_comp=1, mode=vo.MODE_VOIGT4)
+    th = np.stack([rng.uniform(0.1, 1, 6), rng.uniform(-0.5, 0.5, 6), rng.uniform(0.05, 1.1, 6), rng.uniform(0.05, 1.1, 6)], 1)
+    want = vo.log_prob_batch(reg, th)
+    got = hip_ctx.lnprob(th)
+    assert np.isfinite(want).all() and np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) <= 1e-9
+    hip_ctx.sampler_init(th[:2], seed=4, split_block=2)
+    res = hip_ctx.run(5)
+    chain, _, nacc = vo.run_sampler(lambda q: vo.log_prob_batch(reg, q), th[:2], want[:2], 5, seed=4, block=2)
+    assert np.allclose(res["chain"], chain, rtol=1e-10, atol=1e-12) and np.array_equal(res["n_accept"], nacc)
+    empty = hip_ctx.run(0)
+    assert empty["chain"].shape == (0, 2, 4) and np.array_equal(empty["n_accept"], nacc)
+    none_kept = hip_ctx.run(2, thin=5)
+    assert none_kept["chain"].shape == (0, 2, 4)
+    if hip_ctx.packing_request in (16, 65):
+        return                                    # those shapes hold at most 8 components
+    x3 = np.array([-1.0, 0.0, 1.0])
+    f3, n3 = np.array([0.9, 0.2, 0.85]), np.full(3, 0.02)
+    hip_ctx.set_regions(x3, f3, n3, 16, mode=vo.MODE_VOIGT4)
+    reg3 = vo.Region(x=x3, flux=f3, noise=n3, n_comp=16, mode=vo.MODE_VOIGT4)
+    th3 = np.tile(np.array([0.2, 0.0, 0.5, 1.0]), (4, 16)) * (1 + 0.05 * rng.standard_normal((4, 64)))
+    th3[:, 1::4] = rng.uniform(-1, 1, (4, 16))
+    want3 = vo.log_prob_batch(reg3, th3)
+    got3 = hip_ctx.lnprob(th3)
+    assert np.isfinite(want3).all() and np.max(np.abs(got3 - want3) / np.maximum(1, np.abs(want3))) <= 1e-9
+
+
 def test_error_behaviour(hip_ctx):
     import vamp_amd
     g = load_golden("stretch_traj.npz")
