@@ -487,3 +487,31 @@ def test_in_library_exchange_several_ranks_on_one_gpu(world, parts, tmp_path):
         ctx.run(6, store_chain=False)
         X1, lnp1, nacc1, _ = ctx.get_state()
     assert np.array_equal(r["X"], X1) and np.array_equal(r["lnp"], lnp1) and np.array_equal(r["nacc"], nacc1)
+
+
+@pytest.mark.gpu
+def test_pieces_of_a_packed_single_region_ensemble():
+    """A short one-line region with 65 536 walkers runs four walkers per wavefront with draws from
+    k_draws; cut into pieces (the layout of the overlapped exchange) and with the in-library
+    exchange of one rank, the chain is the unsharded one: the draw and pack indices are local to a
+    piece's launch, the slots global."""
+    import vamp_amd
+    from vamp_amd.ensemble import ShardedEnsemble
+    region, _ = _case()
+    rng = np.random.default_rng(21)
+    W = 65536
+    X0 = np.stack([rng.uniform(0.3, 1.5, W), rng.uniform(-4, 4, W), rng.uniform(0.5, 3, W), rng.uniform(2, 8, W)], 1)
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+        ctx.sampler_init(X0, seed=8, split_block=1024)
+        ctx.run(3, store_chain=False)
+        X1, lnp1, nacc1, _ = ctx.get_state()
+    for exchange, single in (("none", False), ("rccl", True)):
+        with vamp_amd.HipContext(device=0) as ctx:
+            ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+            ens = ShardedEnsemble(ctx, X0, seed=8, split_block=1024, exchange=exchange, exchange_single_rank=single, parts=2)
+            assert ens.parts == 2
+            ens.step(1)
+            ens.run_dev(2)
+            X2, lnp2, nacc2, step = ctx.get_state()
+            assert step == 3 and np.array_equal(X2, X1) and np.array_equal(lnp2, lnp1) and np.array_equal(nacc2, nacc1), exchange
