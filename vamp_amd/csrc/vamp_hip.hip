@@ -44,6 +44,12 @@
 #ifndef VAMP_EARLY_LOADS
 #define VAMP_EARLY_LOADS 1
 #endif
+#ifndef VAMP_MID_MIN_K
+#define VAMP_MID_MIN_K 3
+#endif
+#ifndef VAMP_MID_MIN_P
+#define VAMP_MID_MIN_P 96
+#endif
 #ifndef VAMP_X_PREFETCH
 #define VAMP_X_PREFETCH 0
 #endif
@@ -150,7 +156,10 @@ using PackSmall = Pack<16, 8, true, 2>;
 #ifndef VAMP_SMALL2_WAVES
 #define VAMP_SMALL2_WAVES 2
 #endif
-using PackSmall2 = Pack<16, 2, true, VAMP_SMALL2_WAVES>;
+#ifndef VAMP_SMALL2_LANES
+#define VAMP_SMALL2_LANES 8
+#endif
+using PackSmall2 = Pack<VAMP_SMALL2_LANES, 2, true, VAMP_SMALL2_WAVES>;
 // one walker per small workgroup WITH its own Taylor tables (<= 8 lines: 18 KB + 3.7 KB of LDS),
 // no far field; the group's wavefronts share the staging and take contiguous shares of the pixels: the blended regions of real spectra (3..8 lines,
 // ~100..500 px), where every pixel lies in some line's core and the near-axis rule (~190 issue
@@ -1656,7 +1665,7 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     const int* ni = nullptr;
     const double* nd = nullptr;
     // <16 lanes, 8 lines> packing needs every wave inside one region and one shard
-    const int subs = PackSmall::SUBS;
+    const int subs = std::max(PackSmall::SUBS, PackSmall2::SUBS);
     const bool packable = !ext && halfW % subs == 0 && (c->split_block / 2) % subs == 0;
     const size_t ncls = c->classes.size();
     const bool fork = !ext && ncls > 1 && c->concurrent_classes;
@@ -2085,7 +2094,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         for (int r = 0; r < n_regions; ++r) {
             int k = 0;
             if (spectrum_like) {
-                if (R[r].K >= 3 && R[r].P >= 96 && mode != VAMP_GAUSS3 && !c->f32) k = 1;
+                if (R[r].K >= VAMP_MID_MIN_K && R[r].P >= VAMP_MID_MIN_P && mode != VAMP_GAUSS3 && !c->f32) k = 1;
                 else if (R[r].K <= PackSmall2::KCAP) k = 2;
             }
             cls[k].regions.push_back(r);
