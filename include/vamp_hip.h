@@ -73,8 +73,9 @@ int vamp_ctx_synchronize(vamp_ctx* ctx);
  *   64   one walker per wavefront;
  *   256  one walker per 4-wavefront workgroup: each wavefront sweeps every 4th 256-pixel tile and, in
  *        fp64, the line cores are read from per-line Taylor tables shared by the workgroup (long regions);
- *   16   four walkers per wavefront, <= 8 components per region (the short single-line regions of
- *        real spectra; draws come from a one-thread-per-mover launch);
+ *   16   four walkers per wavefront, <= 8 components per region (the short regions of real
+ *        spectra; draws come from a one-thread-per-mover launch; automatic packing uses eight
+ *        walkers per wavefront, 8 lanes each, for regions of one or two components);
  *   65   64 lanes + the walker's own Taylor tables, <= 8 components, no far field (the blended
  *        regions of real spectra: a few lines over a few hundred pixels);
  *   0    choose: contexts that look like a real spectrum (<= 8 components everywhere, mean region
