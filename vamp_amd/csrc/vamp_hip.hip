@@ -44,6 +44,9 @@
 #ifndef VAMP_EARLY_LOADS
 #define VAMP_EARLY_LOADS 1
 #endif
+#ifndef VAMP_BLEND_PASS_LINES
+#define VAMP_BLEND_PASS_LINES 4
+#endif
 #ifndef VAMP_MID_MIN_K
 #define VAMP_MID_MIN_K 3
 #endif
@@ -141,7 +144,12 @@ struct Pack {
     static constexpr int WALKERS_PER_BLOCK = SPLIT_ ? 1 : WPB_ * SUBS;
     // wavefronts per SIMD the register allocation aims for: 3 (<= 168 VGPRs) everywhere except the
     // blend shape, whose 22 KB of LDS per single-wave workgroup allow fewer than 2 anyway
-    static constexpr int MIN_WAVES = (SPLIT_ && TABS_ && !FF_) ? 2 : VAMP_MIN_WAVES;
+    // the blend shape keeps the Taylor tables of only LINES_PER_PASS lines in LDS at a time (0: of all
+    // KCAP lines) and sweeps its pixels once per pass with the optical depths held in registers:
+    // 9 KB instead of 18 KB of tables per walker, 3 instead of 1.7 wavefronts per SIMD
+    static constexpr int LINES_PER_PASS = (SPLIT_ && TABS_ && !FF_ && WPB_ == 1) ? VAMP_BLEND_PASS_LINES : 0;
+    static constexpr int TAB_LINES = LINES_PER_PASS > 0 ? LINES_PER_PASS : KCAP_;
+    static constexpr int MIN_WAVES = (SPLIT_ && TABS_ && !FF_ && LINES_PER_PASS == 0) ? 2 : VAMP_MIN_WAVES;
     static_assert(!SPLIT_ || (LPW_ == 64 && (WPB_ == PARTS || !FF_) && WPB_ <= PARTS),
                   "a split workgroup is PARTS wavefronts on one walker (tile classes), or up to PARTS wavefronts without far field (contiguous shares)");
 };
@@ -935,11 +943,10 @@ struct PixPtrs {
 // over the wave, and the class sums are added in class order -- by this wavefront (SPLIT = false)
 // or through `red` by the PARTS wavefronts of the workgroup (SPLIT = true, `part` = this wave's
 // class): the same order of additions either way.  The tail (pixels beyond the last full tile) belongs to class 0.
-template <bool F32, int MODE, class PK>
+template <bool F32, int MODE, class PK, bool TAB = use_tables<F32, MODE, PK>()>
 __device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
                                             const PixPtrs& px, int lane, int base0, int full, int stride, bool tail, double& chi,
                                             const double* tab) {
-    constexpr bool TAB = use_tables<F32, MODE, PK>();
     if constexpr (F32) {
         const float* x = px.xf + R.pix_off; const float* f = px.ff + R.pix_off; const float* wt = px.wtf + R.pix_off;
         if constexpr (VAMP_FARFIELD && PK::FF && MODE != VAMP_GAUSS3 && TPIX == 4)
@@ -982,6 +989,77 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<
     }
 }
 
+// ---- blends: tables of a few lines at a time, optical depths in registers across the passes -------
+// T pixels per lane (base + 64 t + lane) of lines k0 .. k0 + kn - 1, whose tables sit in `tab`
+template <int MODE, class PK, int T>
+__device__ __forceinline__ void blend_chunk(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x, int lane,
+                                            int base, int k0, int kn, const double* tab, double (&tau)[4]) {
+    double xi[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int i = base + 64 * t + lane;
+        xi[t] = x[i < R.P ? i : R.P - 1];
+    }
+    for (int kk = 0; kk < kn; ++kk) {
+        const LineRec ln = L.line[k0 + kk];
+        double X[T], H[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) X[t] = fabs(xi[t] - ln.c) * ln.s;
+        tile_voigt<T, true>(ln, L.dtab[k0 + kk], X, H, tab + kk * vamp::TAB_LINE);
+#pragma unroll
+        for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
+    }
+}
+template <int MODE, class PK>
+__device__ __forceinline__ void blend_chunk_n(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x, int lane,
+                                              int base, int tn, int k0, int kn, const double* tab, double (&tau)[4]) {
+    if (tn >= 4) blend_chunk<MODE, PK, 4>(R, L, x, lane, base, k0, kn, tab, tau);
+    else if (tn == 3) blend_chunk<MODE, PK, 3>(R, L, x, lane, base, k0, kn, tab, tau);
+    else if (tn == 2) blend_chunk<MODE, PK, 2>(R, L, x, lane, base, k0, kn, tab, tau);
+    else if (tn == 1) blend_chunk<MODE, PK, 1>(R, L, x, lane, base, k0, kn, tab, tau);
+}
+constexpr int BLEND_MAX_PIXELS = 512;     // two chunks of up to 4 pixels per lane
+template <int MODE, class PK>
+__device__ __forceinline__ double sweep_blend_passes(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const PixPtrs& px, int lane,
+                                                     double* tab) {
+    static_assert(PK::WPB == 1 && PK::LPW == 64, "one wavefront per walker");
+    constexpr int LP = PK::LINES_PER_PASS;
+    const double* __restrict__ x = px.x + R.pix_off;
+    const double* __restrict__ f = px.f + R.pix_off;
+    const double* __restrict__ wt = px.wt + R.pix_off;
+    const int P = R.P, K = R.K;
+    const int nt = (P + 63) >> 6;                  // pixels per lane, <= 8
+    const int tn0 = nt < 4 ? nt : 4, tn1 = nt - tn0;
+    double tau0[4] = {0.0, 0.0, 0.0, 0.0}, tau1[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += LP) {
+        const int kn = K - k0 < LP ? K - k0 : LP;
+        // the tables of this pass: one (line, interval) pair per lane and round
+        for (int e = lane; e < kn * vamp::TAB_NI; e += 64) {
+            const int kk = e / vamp::TAB_NI, i = e % vamp::TAB_NI, k = k0 + kk;
+            vamp::taylor_table_row(i, L.line[k].y, L.dtab[k], L.line[k].pole, L.line[k].hy, tab + kk * vamp::TAB_LINE + i * vamp::TAB_NT);
+        }
+        __syncthreads();
+        blend_chunk_n<MODE, PK>(R, L, x, lane, 0, tn0, k0, kn, tab, tau0);
+        if (tn1 > 0) blend_chunk_n<MODE, PK>(R, L, x, lane, 256, tn1, k0, kn, tab, tau1);
+        __syncthreads();                            // the next pass overwrites the tables
+    }
+    double chi = 0.0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 256 * c + 64 * t + lane;
+            if (64 * (4 * c + t) < P) {             // wave-uniform: this pixel slot exists
+                const int idx = i < P ? i : P - 1;
+                const double m = vamp::exp_taylor(-(c == 0 ? tau0[t] : tau1[t]));
+                const double r = (f[idx] - m) * wt[idx];
+                chi += i < P ? r * r : 0.0;
+            }
+        }
+    }
+    return wave_sum<64>(chi);
+}
+
 template <bool F32, int MODE, class PK = PackWide>
 __device__ __forceinline__ double sweep_pixels(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
                                                const PixPtrs& px, int lane, int part, double* red, const double* tab) {
@@ -991,6 +1069,13 @@ __device__ __forceinline__ double sweep_pixels(const RegionDev& R, const WalkerL
         double chi = 0.0;
         sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, 0, full, TILE, true, chi, tab);
         return wave_sum<PK::LPW>(chi);
+    } else if constexpr (PK::LINES_PER_PASS > 0 && use_tables<F32, MODE, PK>()) {
+        if (R.P <= BLEND_MAX_PIXELS) return sweep_blend_passes<MODE, PK>(R, L, px, lane, const_cast<double*>(tab));
+        // longer than the registers hold (only when this shape is forced on a long region): every
+        // line through the per-pixel evaluator, no tables
+        double chi = 0.0;
+        sweep_class<F32, MODE, PK, false>(R, L, Sx, dct, px, lane, 0, full, TILE, true, chi, nullptr);
+        return wave_sum<64>(chi);
     } else if constexpr (PK::SPLIT && !PK::FF) {
         // a blend of a few hundred pixels: the group's wavefronts take contiguous shares of the region
         // (whole 16-pixel runs), each swept as full tiles + one iteration of 1..4 pixels per lane
@@ -1046,7 +1131,7 @@ __device__ __forceinline__ double loglike_from_sum(const RegionDev& R, const LDS
 template <bool F32, int MODE, class PK = PackWide>
 __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* dct,
                                               const PixPtrs& px, int lane, double* chi_out, int part, double* red, double* tab) {
-    const double lp = stage_lines<MODE, PK, use_tables<F32, MODE, PK>()>(R, L, lane, F32, part, tab);
+    const double lp = stage_lines<MODE, PK, use_tables<F32, MODE, PK>() && PK::LINES_PER_PASS == 0>(R, L, lane, F32, part, tab);
     if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
         if (chi_out) *chi_out = __builtin_nan("");
         return NEG_INF;
@@ -1079,7 +1164,7 @@ __global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_lnprob(const Reg
     __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
     __shared__ double dct[PK::FF ? FF_TABLE : 1];
     __shared__ double red[PARTS];
-    __shared__ LineTables<use_tables<F32, MODE, PK>(), PK::KCAP> tabs[PK::SPLIT ? 1 : PK::WPB];
+    __shared__ LineTables<use_tables<F32, MODE, PK>(), PK::TAB_LINES> tabs[PK::SPLIT ? 1 : PK::WPB];
     if constexpr (PK::FF) ff_fill_table(dct);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
@@ -1310,7 +1395,7 @@ __global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_half_step(Sample
     __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
     __shared__ double dct[PK::FF ? FF_TABLE : 1];
     __shared__ double red[PARTS];
-    __shared__ LineTables<use_tables<F32, MODE, PK>(), PK::KCAP> tabs[PK::SPLIT ? 1 : PK::WPB];
+    __shared__ LineTables<use_tables<F32, MODE, PK>(), PK::TAB_LINES> tabs[PK::SPLIT ? 1 : PK::WPB];
     if constexpr (PK::FF) ff_fill_table(dct);
     const int lane = threadIdx.x & 63;
     // the wave index is the same in every lane: say so, and the draws below (Philox rounds, the
@@ -2094,7 +2179,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         for (int r = 0; r < n_regions; ++r) {
             int k = 0;
             if (spectrum_like) {
-                if (R[r].K >= VAMP_MID_MIN_K && R[r].P >= VAMP_MID_MIN_P && mode != VAMP_GAUSS3 && !c->f32) k = 1;
+                if (R[r].K >= VAMP_MID_MIN_K && R[r].P >= VAMP_MID_MIN_P && R[r].P <= BLEND_MAX_PIXELS && mode != VAMP_GAUSS3 && !c->f32) k = 1;
                 else if (R[r].K <= PackSmall2::KCAP) k = 2;
             }
             cls[k].regions.push_back(r);
