@@ -76,10 +76,11 @@ int vamp_ctx_synchronize(vamp_ctx* ctx);
  *   16   four walkers per wavefront, <= 8 components per region (the short regions of real
  *        spectra; draws come from a one-thread-per-mover launch; automatic packing uses eight
  *        walkers per wavefront, 8 lanes each, for regions of one or two components);
- *   65   64 lanes + the walker's own Taylor tables, <= 8 components, no far field (the blended
- *        regions of real spectra: a few lines over a few hundred pixels);
+ *   65   64 lanes + the walker's own Taylor tables (four lines' at a time), <= 8 components, no far
+ *        field (the blended regions of real spectra: a few lines over a few hundred pixels; regions
+ *        of more than 512 pixels fall back to per-pixel evaluation without tables);
  *   0    choose: contexts that look like a real spectrum (<= 8 components everywhere, mean region
- *        <= 128 pixels) are split into two launch classes -- regions with >= 3 components over >= 96
+ *        <= 128 pixels) are split into launch classes -- regions with >= 3 components over 96..512
  *        pixels run as 65, the rest as 16 (64 in launches of fewer than 16 384 walkers); otherwise
  *        256 when every region has >= 2048 pixels, else 64.
  * The choice never depends on how an ensemble is sharded, so a shard runs the arithmetic of the
