@@ -71,7 +71,9 @@ class _EnsembleMCMC:
 
     def __init__(self, fit):
         self._fit = fit
-        self._traces = {}
+        self._flat = None          # [samples, D] in the caller's units; traces are columns, cut on demand
+        self._names = []
+        self._derived = {}         # name -> (source column name, function): est_sigma_k in Voigt mode
         self.DIC = None
         self.BPIC = None
         self.acceptance_fraction = None
@@ -80,8 +82,22 @@ class _EnsembleMCMC:
     def sample(self, iter, burn=0, thin=1, progress_bar=False, **_ignored):
         self._fit._run_sampler(int(iter), int(burn), int(thin))
 
+    def _samples(self, name):
+        if name in self._derived:
+            src, fn = self._derived[name]
+            return fn(self._samples(src))
+        return self._flat[:, self._names.index(name)].copy()
+
+    @property
+    def _traces(self):
+        """name -> samples for every trace (materialised on demand: a batched model-selection ladder
+        builds thousands of fits whose traces are never read)"""
+        return {nm: self._samples(nm) for nm in list(self._names) + list(self._derived)}
+
     def trace(self, name):
-        return _Trace(self._traces[name])
+        if name not in self._names and name not in self._derived:
+            raise KeyError(name)
+        return _Trace(self._samples(name))
 
     def stats(self):
         out = {}
@@ -379,10 +395,10 @@ class VPfit():
         flat_dev = chain.reshape(-1, self._ndim)
         flat = self._to_caller(flat_dev)
         mc_ = self.mcmc
-        mc_._traces = {nm: flat[:, j].copy() for j, nm in enumerate(self._names)}
+        mc_._flat, mc_._names, mc_._derived = flat, list(self._names), {}
         if self._voigt:      # the reference's callers ask for est_sigma_k in Voigt mode too (vpspectrum.py:400)
             for k in range(self._n):
-                mc_._traces["est_sigma_%d" % k] = self.GaussianWidth(mc_._traces["est_G_%d" % k])
+                mc_._derived["est_sigma_%d" % k] = ("est_G_%d" % k, self.GaussianWidth)
         mc_.acceptance_fraction = float(np.mean(n_accept)) / max(1, steps)
         mc_.walker_steps_per_second = W * keep / seconds if seconds > 0 else float("nan")
         # information criteria from the chain (every kept sample scored on the device)
