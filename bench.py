@@ -314,9 +314,40 @@ def main():
     ctx.set_regions(wl["x"], wl["flux"], wl["noise"], K, mode=wl["mode"], nbz=wl["nbz"])
 
     from vamp_amd.ensemble import ShardedEnsemble
-    ens = ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange="rccl" if dist is not None else "none",
-                          exchange_single_rank=args.force_dist)
+    exchange_label = "none"
+    try:
+        ens = ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange="rccl" if dist is not None else "none",
+                              exchange_single_rank=args.force_dist)
+        comm_error = None
+    except vamp_amd._lib.VampError as e:
+        if e.code != -3:                  # anything but a communicator problem is a bug: fail
+            raise
+        ens, comm_error = None, str(e)
+    if dist is not None:
+        # a communicator that did not come up on ANY rank sends every rank to the host-staged exchange:
+        # same kernels, rows through pinned host memory and gloo -- slow, loudly labelled, but the
+        # scaling run still produces a correct line instead of none
+        flag = torch.tensor([0 if ens is None else 1])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            if rank == 0:
+                print("bench.py: RCCL communicator failed (%s); FALLING BACK to the host-staged gloo exchange" % comm_error,
+                      file=sys.stderr, flush=True)
+            ctx.close()
+            ctx = vamp_amd.HipContext(device=local_rank, dtype=dtype)
+            ctx.set_regions(wl["x"], wl["flux"], wl["noise"], K, mode=wl["mode"], nbz=wl["nbz"])
+            ens = ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange="gloo_host", parts=1)
+            exchange_label = "FALLBACK: host-staged gloo all-gather (RCCL communicator failed: %s)" % comm_error
+        else:
+            exchange_label = f"in-library RCCL all-gather of the active colour, {ens.parts} piece(s) per half-step"
     own = ens.own_count
+    host_staged = ens.exchange == "gloo_host"
+
+    def run_steps(n, thin=1, chain_ptr=None):
+        if host_staged:
+            ens.step(n)                   # stepped from Python, no device-resident chain in this mode
+        else:
+            ens.run_dev(n, thin=thin, chain_ptr=chain_ptr)
 
     def sync_all():
         ctx.synchronize()
@@ -328,14 +359,14 @@ def main():
 
     # chain storage (device resident, torch = allocator): every kept step is one device-to-device copy
     # of the state on the stream the kernels run on, inside the timed region
-    chain = None if args.no_chain else torch.empty((args.steps, W * D), dtype=torch.float64, device=dev)
+    chain = None if (args.no_chain or host_staged) else torch.empty((args.steps, W * D), dtype=torch.float64, device=dev)
 
-    ens.run_dev(args.warmup)
+    run_steps(args.warmup)
     sync_all()
     quiet.__exit__()
     ctx.kernel_timing(True)
     t0 = time.perf_counter()
-    ens.run_dev(args.steps, chain_ptr=None if chain is None else chain.data_ptr())
+    run_steps(args.steps, chain_ptr=None if chain is None else chain.data_ptr())
     sync_all()
     dt = time.perf_counter() - t0
     k_ms, k_n = ctx.kernel_timing(False)
@@ -350,7 +381,7 @@ def main():
         sync_all()
         ctx.kernel_timing(True)
         t0 = time.perf_counter()
-        ens.run_dev(n_s, thin=thin, chain_ptr=None if chain is None else chain.data_ptr())
+        run_steps(n_s, thin=thin, chain_ptr=None if chain is None else chain.data_ptr())
         sync_all()
         dts = time.perf_counter() - t0
         s_ms, s_n = ctx.kernel_timing(False)
@@ -404,7 +435,7 @@ def main():
                                    f"stretch move a=2, walkers sharded over {world} GPU(s)",
                        "pixels": P, "components": K, "walkers": W, "ndim": D, "parameterisation": args.param,
                        "chain_recorded": chain is not None,
-                       "exchange": "none" if dist is None else f"in-library RCCL all-gather of the active colour, {ens.parts} piece(s) per half-step"},
+                       "exchange": exchange_label},
             # contract form: ALGORITHMIC bytes of the launch / its HIP-event duration, against the HBM peak.
             # The kernel is not HBM-bound (the spectrum is shared by all walkers and stays in L2: see
             # `traffic`); its binding roof is fp64 VALU issue, reported in `valu` below.
