@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "vamp_hip.hip")
 OUT = os.path.join(HERE, "libvamp_hip.so")
-DEPS = [SRC, os.path.join(HERE, "csrc", "voigt_math.hpp"), os.path.join(HERE, "csrc", "map_search.hpp"), os.path.join(HERE, "..", "include", "vamp_hip.h")]
+DEPS = [SRC, os.path.join(HERE, "csrc", "ff_matrix.inc"), os.path.join(HERE, "csrc", "voigt_math.hpp"), os.path.join(HERE, "csrc", "map_search.hpp"), os.path.join(HERE, "..", "include", "vamp_hip.h")]
 
 
 def build(force=False, verbose=True):

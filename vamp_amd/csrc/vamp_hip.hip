@@ -185,6 +185,7 @@ constexpr int FF_NODES = 16;          // Chebyshev nodes of the far-field interp
 #define VAMP_FF_DIST 4.0
 #endif
 constexpr double FF_DIST = VAMP_FF_DIST;   // a line is "far" from a tile when it lies >= FF_DIST half-widths beyond its edge
+#include "ff_matrix.inc"               // FF_M, FF_DEG, FF_ROWS, FF_MAT (tools/gen_ff_matrix.py)
 
 template <int KCAP>
 struct WalkerLds {
@@ -193,8 +194,10 @@ struct WalkerLds {
     double dtab[KCAP][vamp::DTAB_N];
     float linef[KCAP][4];  // fp32 path: c, s, y, amp
 };
-struct TileScratch {        // per wavefront: far-field working set of the tile in flight
-    double ffval[FF_NODES]; // optical depth of the far lines at the tile's Chebyshev nodes, then its coefficients
+struct alignas(16) TileScratch {   // per wavefront: far-field working set of the tile in flight
+    double coef[FF_ROWS];   // optical depth of the far lines at the tile's 16 Chebyshev nodes, then (every lane has
+                            // read the node values by then) the tile's four local power series, one per quarter,
+                            // 14 coefficients each; fp32 contexts store those as floats in the same space
     int farlist[KMAX];      // lines treated through the far field
 };
 // Taylor tables of the near-axis zone of every line of ONE walker (voigt_math.hpp): 36 KiB, which
@@ -344,22 +347,22 @@ __device__ __forceinline__ void tile_jfrac(const double (&X)[T], const double (&
     if (t < T) H[t] = vamp::voigt_jfrac<M>(X[t], y, r2[t]);
 }
 
-// sqrt(pi) H from the line's Taylor table, 0 <= x < 8: nine 16-byte LDS reads + 17 fused multiply-adds
+// sqrt(pi) H from the line's Taylor table, 0 <= x < 8: TAB_NT / 2 16-byte LDS reads + TAB_NT - 1 fused multiply-adds
 __device__ __forceinline__ double table_eval(const double* tab, double x) {
     const int i = (int)(x * 2.0);
     const double d = fma((double)i, -vamp::CORE_H, x) - 0.5 * vamp::CORE_H;
-    static_assert(vamp::TAB_NT == 18, "nine coefficient pairs below");
+    static_assert(vamp::TAB_NT % 2 == 0, "coefficient pairs below");
+    constexpr int NP = vamp::TAB_NT / 2;
     const double2* a = reinterpret_cast<const double2*>(tab + i * vamp::TAB_NT);
-    const double2 c8 = a[8], c7 = a[7], c6 = a[6], c5 = a[5], c4 = a[4], c3 = a[3], c2 = a[2], c1 = a[1], c0 = a[0];
-    double r = fma(c8.y, d, c8.x);
-    r = fma(r, d, c7.y); r = fma(r, d, c7.x);
-    r = fma(r, d, c6.y); r = fma(r, d, c6.x);
-    r = fma(r, d, c5.y); r = fma(r, d, c5.x);
-    r = fma(r, d, c4.y); r = fma(r, d, c4.x);
-    r = fma(r, d, c3.y); r = fma(r, d, c3.x);
-    r = fma(r, d, c2.y); r = fma(r, d, c2.x);
-    r = fma(r, d, c1.y); r = fma(r, d, c1.x);
-    r = fma(r, d, c0.y); r = fma(r, d, c0.x);
+    double2 c[NP];
+#pragma unroll
+    for (int n = NP - 1; n >= 0; --n) c[n] = a[n];
+    double r = fma(c[NP - 1].y, d, c[NP - 1].x);
+#pragma unroll
+    for (int n = NP - 2; n >= 0; --n) {
+        r = fma(r, d, c[n].y);
+        r = fma(r, d, c[n].x);
+    }
     return r;
 }
 
@@ -517,33 +520,21 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<
 // Bernstein ellipse parameter 5 + sqrt(24) = 9.9 for FF_DIST = 4, and 9.9^-16 = 1.2e-16).  Polynomials add, so ALL far lines of the tile share one interpolant:
 //   1. the (node, far line) pairs -- 16 nodes x up to 16 lines -- are spread over the 64 lanes
 //      (lane = 16 * (line slot) + node) and evaluated with the same Voigt code, 4 lines per pass;
-//   2. node values are summed over lines (two xor shuffles), turned into Chebyshev coefficients
-//      by a 16 x 16 DCT held in LDS (one row per lane), and
-//   3. every pixel of the tile evaluates ONE Clenshaw recurrence (32 instructions) instead of
-//      ~27 instructions per far line.
+//   2. node values are summed over lines (two xor shuffles) and turned by ONE 56 x 16 matrix held in
+//      LDS (one row per lane, tools/gen_ff_matrix.py) into four local power series, one per quarter
+//      of the tile -- a lane holds one pixel of each quarter -- with 14 coefficients each: seen from
+//      a quarter's centre the far lines are >= 17 quarter half-widths away, the coefficients fall
+//      like 17^-j and the terms beyond u^13 are < 1e-17 of the value;
+//   3. every pixel of the tile runs Horner's rule on its quarter's series: 13 fused multiply-adds
+//      (Clenshaw's recurrence on the tile's Chebyshev coefficients cost 30) instead of ~27
+//      instructions per far line.
 // On the headline workload ~90 % of the (pixel, line) evaluations are far: 64 wave-evaluations
 // per tile shrink to ~6 direct ones + ~4 at the nodes.
-constexpr int FF_TABLE = FF_NODES * FF_NODES + FF_NODES;   // DCT matrix [j][m] followed by the node abscissae
+constexpr int FF_TABLE = FF_MAT + FF_NODES;   // the matrix [n/2][lane][n%2] followed by the node abscissae
 
-// cos(pi k / 32) for any integer k, through an exact integer reduction to k in [0, 16]
-__device__ __forceinline__ double ff_cos_pi32(int k) {
-    k &= 63;
-    if (k > 32) k = 64 - k;
-    double sgn = 1.0;
-    if (k > 16) { k = 32 - k; sgn = -1.0; }
-    return sgn * vamp::cos_small((double)k * 9.81747704246810387019e-02);     // pi / 32
-}
-
-// every thread of the workgroup fills its share; call before any thread can leave the kernel
+// every thread of the workgroup copies its share; call before any thread can leave the kernel
 __device__ __forceinline__ void ff_fill_table(double* dct) {
-    for (int e = threadIdx.x; e < FF_TABLE; e += blockDim.x) {
-        if (e < FF_NODES * FF_NODES) {
-            const int j = e / FF_NODES, m = e % FF_NODES;            // (2/16) cos(m pi (j + 1/2) / 16)
-            dct[e] = (2.0 / FF_NODES) * ff_cos_pi32(m * (2 * j + 1));
-        } else {
-            dct[e] = ff_cos_pi32(2 * (e - FF_NODES * FF_NODES) + 1);  // cos(pi (j + 1/2) / 16)
-        }
-    }
+    for (int e = threadIdx.x; e < FF_TABLE; e += blockDim.x) dct[e] = FF_M[e];
     __syncthreads();
 }
 
@@ -606,14 +597,33 @@ __device__ __forceinline__ unsigned long long ff_classify(TileScratch& Sx, int K
                            : __builtin_popcountll(deepmask) + __builtin_popcountll(farmask & ~deepmask & below)] = lane;
     return farmask;
 }
-// (b) optical depth of the far lines at the tile's Chebyshev nodes -> Chebyshev coefficients in Sx.ffval
+// node sums (lanes 0..15 hold them) -> the four local power series of the tile: lane l = 14 q + j < 56 owns
+// coefficient j of quarter q, a = sum_n M[l][n] f_n, stored in the pixel arithmetic type
+template <class real>
+__device__ __forceinline__ void ff_series(TileScratch& Sx, const double* __restrict__ dct, int lane, double fs) {
+    if (lane < FF_NODES) Sx.coef[lane] = fs;
+    __builtin_amdgcn_wave_barrier();
+    const double2* mrow = reinterpret_cast<const double2*>(dct) + (lane < FF_ROWS ? lane : FF_ROWS - 1);
+    const double2* fv = reinterpret_cast<const double2*>(Sx.coef);
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int n2 = 0; n2 < FF_NODES / 2; ++n2) {
+        const double2 m = mrow[n2 * FF_ROWS], f2 = fv[n2];
+        a0 = fma(m.x, f2.x, a0);
+        a1 = fma(m.y, f2.y, a1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < FF_ROWS) reinterpret_cast<real*>(Sx.coef)[lane] = (real)(a0 + a1);
+    __builtin_amdgcn_wave_barrier();
+}
+// (b) optical depth of the far lines at the tile's Chebyshev nodes -> the tile's local power series in Sx.coef
 //     W4NODES (fp32 contexts): node values through Humlicek's W4 in fp32 -- every far point has
 //     |x| + y >= 8, so region II (or I, wave-uniform) applies; transform and coefficients stay fp64
 template <int KCAP, bool W4NODES = false>
 __device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
                                                 int lane, int nfar, double mid, double half) {
     const int node = lane & (FF_NODES - 1), grp = lane >> 4;
-    const double tnode = dct[FF_NODES * FF_NODES + node];          // cos(pi (node + 1/2) / 16)
+    const double tnode = dct[FF_MAT + node];                       // cos(pi (node + 1/2) / 16)
     __builtin_amdgcn_wave_barrier();
     // 1. lane = (slot group, node), four lines per lane (line q = 4 t + group of the compacted far list)
     const double xnode = fma(half, tnode, mid);
@@ -640,14 +650,7 @@ __device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileSc
         double fs = (double)fsf;
         fs += __shfl_xor(fs, 16, 64);
         fs += __shfl_xor(fs, 32, 64);
-        if (lane < FF_NODES) Sx.ffval[lane] = fs;
-        __builtin_amdgcn_wave_barrier();
-        double cm = 0.0;
-#pragma unroll
-        for (int j = 0; j < FF_NODES; ++j) cm = fma(dct[j * FF_NODES + node], Sx.ffval[j], cm);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < FF_NODES) Sx.ffval[lane] = cm;
-        __builtin_amdgcn_wave_barrier();
+        ff_series<float>(Sx, dct, lane, fs);
         return;
     }
     double Xn[4], yn[4], an[4];
@@ -674,40 +677,31 @@ __device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileSc
     }
     fs += __shfl_xor(fs, 16, 64);
     fs += __shfl_xor(fs, 32, 64);
-    // 2. c_m = (2/16) sum_j f_j cos(m pi (j + 1/2) / 16); lane m owns row m
-    if (lane < FF_NODES) Sx.ffval[lane] = fs;
-    __builtin_amdgcn_wave_barrier();
-    double cm = 0.0;
-#pragma unroll
-    for (int j = 0; j < FF_NODES; ++j) cm = fma(dct[j * FF_NODES + node], Sx.ffval[j], cm);
-    __builtin_amdgcn_wave_barrier();
-    if (lane < FF_NODES) Sx.ffval[lane] = cm;
-    __builtin_amdgcn_wave_barrier();
+    ff_series<double>(Sx, dct, lane, fs);
 }
-// (c) Clenshaw at the tile's pixels, added to tau (in the pixel arithmetic type)
+// (c) Horner's rule at the tile's pixels, added to tau (in the pixel arithmetic type).  Register t of a
+//     lane is pixel 64 t + lane of the tile: quarter t of an ascending grid, 3 - t of a descending one.
 template <class real, int T>
-__device__ __forceinline__ void ff_clenshaw(const TileScratch& Sx, const real (&xi)[T], double mid, double half, real (&tau)[T]) {
-    const real inv_half = (real)(1.0 / half), rmid = (real)mid;
-    real tt2[T], b1[T], b2[T];
+__device__ __forceinline__ void ff_horner(const TileScratch& Sx, const real (&xi)[T], double mid, double half, bool up,
+                                          real (&tau)[T]) {
+    static_assert(T == 4, "one pixel per quarter of the tile");
+    const real scale = (real)(4.0 * vamp::rcp_nr(half));     // (a last-bit error in the scale moves u by 1e-16)
+    real u[T], acc[T];
+    const real* cq[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        tt2[t] = (real)2 * ((xi[t] - rmid) * inv_half);
-        b1[t] = (real)0;
-        b2[t] = (real)0;
+        const int q = up ? t : T - 1 - t;
+        cq[t] = reinterpret_cast<const real*>(Sx.coef) + q * (FF_DEG + 1);
+        u[t] = (xi[t] - (real)fma(half, 0.5 * q - 0.75, mid)) * scale;
+        acc[t] = cq[t][FF_DEG];
     }
 #pragma unroll
-    for (int m = FF_NODES - 1; m >= 1; --m) {
-        const real c = (real)Sx.ffval[m];
+    for (int j = FF_DEG - 1; j >= 0; --j) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const real b0 = fma(tt2[t], b1[t], c - b2[t]);
-            b2[t] = b1[t];
-            b1[t] = b0;
-        }
+        for (int t = 0; t < T; ++t) acc[t] = fma(acc[t], u[t], cq[t][j]);
     }
-    const real c0h = (real)(0.5 * Sx.ffval[0]);
 #pragma unroll
-    for (int t = 0; t < T; ++t) tau[t] += fma((real)0.5 * tt2[t], b1[t], c0h - b2[t]);
+    for (int t = 0; t < T; ++t) tau[t] += acc[t];
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -726,7 +720,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
     const double my_w25 = sqrt(fmax(vamp::R2_M3 - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
 #if VAMP_X_PREFETCH
     // the abscissae of a tile are requested one tile ahead: they head every dependency chain of the
-    // tile (classification, near lines, Clenshaw), and an L2 round trip at the top of each of the
+    // tile (classification, near lines, far-field series), and an L2 round trip at the top of each of the
     // 16 iterations is paid by all the wavefronts of a workgroup together
     double xn[T], xn_lo = 0.0, xn_hi = 0.0;
     if (base0 < base1) {
@@ -778,7 +772,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
             for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
         }
 #endif
-        // flux and weights of the tile are requested here, ahead of the Clenshaw recurrence and the
+        // flux and weights of the tile are requested here, ahead of the far-field series and the
         // exponentials that separate them from their use: left to itself the compiler sinks each
         // load to its use and the wavefront sits through eight L2 round trips per tile
         double fi[T], wi[T];
@@ -794,7 +788,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifndef VAMP_SKIP_CLENSHAW
-        if (nfar > 0) ff_clenshaw<double, T>(Sx, xi, mid, half, tau);
+        if (nfar > 0) ff_horner<double, T>(Sx, xi, mid, half, x_hi > x_lo, tau);
 #endif
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -885,7 +879,7 @@ __device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const Walker
 
 // fp32 sweep of full tiles with the far field: near lines through W4 in fp32, all far lines through
 // the tile's interpolant -- node values and cosine transform in fp64 (one evaluation per lane,
-// same code as the fp64 path), Clenshaw per pixel in fp32.
+// same code as the fp64 path), transform in fp64, Horner per pixel in fp32.
 template <int MODE, class PK>
 __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx,
                                                    const double* __restrict__ dct, const float* __restrict__ x,
@@ -921,7 +915,7 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const Wal
         }
         if (nfar > 0) {
             ff_coefficients<PK::KCAP, true>(L, Sx, dct, lane, nfar, mid, half);
-            ff_clenshaw<float, T>(Sx, xi, mid, half, tau);
+            ff_horner<float, T>(Sx, xi, mid, half, x_hi > x_lo, tau);
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -1162,7 +1156,7 @@ __global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_lnprob(const Reg
     if (all) region = region_list ? region_list[blockIdx.y] : (int)blockIdx.y;
     __shared__ WalkerLds<PK::KCAP> lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
     __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
-    __shared__ double dct[PK::FF ? FF_TABLE : 1];
+    __shared__ alignas(16) double dct[PK::FF ? FF_TABLE : 1];
     __shared__ double red[PARTS];
     __shared__ LineTables<use_tables<F32, MODE, PK>(), PK::TAB_LINES> tabs[PK::SPLIT ? 1 : PK::WPB];
     if constexpr (PK::FF) ff_fill_table(dct);
@@ -1393,7 +1387,7 @@ __global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_half_step(Sample
     constexpr bool EXT = DRAWS == DRAW_HOST;
     __shared__ WalkerLds<PK::KCAP> lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
     __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
-    __shared__ double dct[PK::FF ? FF_TABLE : 1];
+    __shared__ alignas(16) double dct[PK::FF ? FF_TABLE : 1];
     __shared__ double red[PARTS];
     __shared__ LineTables<use_tables<F32, MODE, PK>(), PK::TAB_LINES> tabs[PK::SPLIT ? 1 : PK::WPB];
     if constexpr (PK::FF) ff_fill_table(dct);

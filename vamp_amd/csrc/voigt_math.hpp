@@ -333,7 +333,7 @@ VAMP_DEV double voigt_core(double x, double y, const double* dtab, double pole, 
 // For one line (fixed y) sqrt(pi) Re w(x + i y) on 0 <= x < 8 is an entire function of x.  The zone
 // is cut into TAB_NI intervals of width 1/2 (their centres x_i = (i + 1/2)/2 are nodes of the
 // near-axis rule, so the rule needs no exponentials there: the weights are e^{-j^2/4}), and on
-// each the function is its Taylor polynomial of degree TAB_NT - 1 about x_i:
+// each the function is its Taylor polynomial of degree TAB_NC - 1 about x_i, economised to degree TAB_NT - 1:
 //     Ws = sqrt(pi) w,  Ws' = -2 z Ws + 2i,  c_0 = Ws(z_i),  c_1 = -2 z_i c_0 + 2i,
 //     c_{n+1} = -2 (z_i c_n + c_{n-1}) / (n + 1),      sqrt(pi) H(x_i + d, y) = sum_n Re(c_n) d^n
 // (d real, |d| <= 1/4).  Measured against 40-digit references for y from 1e-12 to 8: absolute
@@ -341,8 +341,27 @@ VAMP_DEV double voigt_core(double x, double y, const double* dtab, double pole, 
 // TAB_NT - 1 fused multiply-adds on coefficients read from LDS, against ~180 issue slots for the
 // rule itself; a table costs one rule evaluation (real and imaginary part) per interval.
 constexpr int TAB_NI = 16;            // intervals: [i/2, (i+1)/2)
-constexpr int TAB_NT = 18;            // coefficients per interval (144 B: 16-byte aligned rows)
+constexpr int TAB_NC = 18;            // Taylor coefficients computed per interval
+#ifndef VAMP_TAB_NT
+#define VAMP_TAB_NT 14
+#endif
+constexpr int TAB_NT = VAMP_TAB_NT;   // coefficients kept per interval (112 B: 16-byte aligned rows)
 constexpr int TAB_LINE = TAB_NI * TAB_NT;   // doubles per line
+// Chebyshev economisation on |d| <= 1/4: the terms d^14 .. d^17 are replaced by their best lower-degree
+// stand-ins (d^n = h^n [T_n(d/h) / 2^(n-1) - lower powers], T_n dropped, highest first), which folds
+// c_14 .. c_17 into the coefficients of the same parity: c'_j = c_j + sum_n E[n - 14][j / 2] c_n, exact
+// dyadic factors.  The degree-13 polynomial that remains differs from the degree-17 one by
+// sum_n |c_n| 4^-n 2^(1-n) < 1e-17: four multiply-adds and two 16-byte reads less per evaluation.
+static_assert(TAB_NT == 14 || TAB_NT == 18, "economised (14) or plain (18) Taylor rows");
+constexpr double TAB_ECON[4][7] = {
+    {4.54747350886464119e-13, -7.13043846189975739e-10, 1.82539224624633789e-07, -1.75237655639648438e-05,
+     8.01086425781250000e-04, -1.87988281250000000e-02, 2.18750000000000000e-01},
+    {3.41060513164848089e-12, -2.03726813197135925e-09, 3.52039933204650879e-07, -2.68220901489257812e-05,
+     1.04904174804687500e-03, -2.19726562500000000e-02, 2.34375000000000000e-01},
+    {1.06581410364015028e-13, -1.63709046319127083e-10, 4.07453626394271851e-08, -3.75509262084960938e-06,
+     1.60932540893554688e-04, -3.35693359375000000e-03, 2.92968750000000000e-02},
+    {8.45545855554519221e-13, -4.94765117764472961e-10, 8.31205397844314575e-08, -6.07967376708984375e-06,
+     2.22921371459960938e-04, -4.15039062500000000e-03, 3.32031250000000000e-02}};
 
 // sin and cos together, same reduction and kernels as cos_small
 VAMP_DEV void sincos_small(double a, double& sn_out, double& cs_out) {
@@ -434,32 +453,37 @@ VAMP_DEV void taylor_table_row(int i, double y, const double* dtab, double pole,
     // c_1 = -2 z c_0 + 2i
     double c1r = -2.0 * (zr * c0r - zi * c0i);
     double c1i = fma(-2.0, fma(zr, c0i, zi * c0r), 2.0);
-    out[0] = c0r;
-    out[1] = c1r;
+    double cr[TAB_NC];
+    cr[0] = c0r;
+    cr[1] = c1r;
     // (unrolled, so that -2/(n+1) is a literal: left as a loop this was a 35-instruction fp64 divide per
     // coefficient -- more than the rest of the table row together)
 #ifdef VAMP_TT_NOREC         // timing-only builds (tools/variants.py)
-    for (int n = 1; n + 1 < TAB_NT; ++n) out[n + 1] = c1i;
+    for (int n = 0; n < TAB_NT; ++n) out[n] = c1i;
     return;
 #endif
-#ifdef VAMP_TT_NOSTORE       // timing-only builds: all the arithmetic, one store per row
-    double acc = 0.0;
-#endif
 #pragma unroll
-    for (int n = 1; n + 1 < TAB_NT; ++n) {
+    for (int n = 1; n + 1 < TAB_NC; ++n) {
         const double f = -2.0 / (double)(n + 1);
         const double nr = f * (fma(zr, c1r, -zi * c1i) + c0r);
         const double ni = f * (fma(zr, c1i, zi * c1r) + c0i);
         c0r = c1r; c0i = c1i;
         c1r = nr; c1i = ni;
-#ifdef VAMP_TT_NOSTORE
-        acc += nr;
-#else
-        out[n + 1] = nr;
-#endif
+        cr[n + 1] = nr;
     }
-#ifdef VAMP_TT_NOSTORE
+#pragma unroll
+    for (int n = TAB_NT; n < TAB_NC; ++n) {
+#pragma unroll
+        for (int m = 0; m < 7; ++m) cr[(n & 1) + 2 * m] = fma(TAB_ECON[n - 14][m], cr[n], cr[(n & 1) + 2 * m]);
+    }
+#ifdef VAMP_TT_NOSTORE       // timing-only builds: all the arithmetic, one store per row
+    double acc = 0.0;
+#pragma unroll
+    for (int n = 0; n < TAB_NT; ++n) acc += cr[n];
     out[2] = acc;
+#else
+#pragma unroll
+    for (int n = 0; n < TAB_NT; ++n) out[n] = cr[n];
 #endif
 }
 
