@@ -405,13 +405,14 @@ def main():
         b_alg = algorithmic_bytes_per_walker_step(P, D, s)
         per_launch_units = own // (2 * ens.parts)       # walker-steps of one half-step launch on this rank
         avg_ms = k_ms / max(1, k_n)
-        traffic = valu_instr = pmc_src = None
+        traffic = valu_instr = valu_busy = pmc_src = None
         try:      # counters of this same command from the committed PMC passes (tools/pmc.sh; separate runs)
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             c = pj["config"]
             if dist is None and (c["pixels"], c["components"], c["walkers"], c["ndim"], c["n_gpus"], c["dtype"]) == (P, K, W, D, world, args.dtype):
                 traffic = (2.0 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024.0
                 valu_instr = pj.get("SQ_INSTS_VALU_per_launch")
+                valu_busy = pj.get("valu_busy_frac_pmc")
                 pmc_src = pj.get("source")
         except (OSError, KeyError, ValueError):
             pass
@@ -454,6 +455,11 @@ def main():
                              "peak_lane_instr_per_s": VALU_PEAK_LANE_INSTR,
                              "executed_lane_instr_per_s": valu_instr * 64 / (avg_ms * 1e-3),
                              "valu_issue_frac": valu_instr * 64 / (avg_ms * 1e-3) / VALU_PEAK_LANE_INSTR,
+                             "valu_busy_frac_pmc": valu_busy,
+                             "valu_busy_is": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), both from the "
+                                             "committed PMC passes: the share of SIMD cycles with a VALU instruction in flight "
+                                             "(a little above the issue fraction: reciprocals and integer multiplies take more "
+                                             "than one 4-cycle pass)",
                              "formula": "SQ_INSTS_VALU (wave instructions per launch, committed PMC pass) x 64 lanes / launch time "
                                         "/ (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz)"},
                          "flops": {"F_w": F_W_FLOPS, "F_px": F_PX_FLOPS, "flop_per_walker_step": flop_ws,

@@ -198,7 +198,9 @@ struct alignas(16) TileScratch {   // per wavefront: far-field working set of th
     double coef[FF_ROWS];   // optical depth of the far lines at the tile's 16 Chebyshev nodes, then (every lane has
                             // read the node values by then) the tile's four local power series, one per quarter,
                             // 14 coefficients each; fp32 contexts store those as floats in the same space
-    int farlist[KMAX];      // lines treated through the far field
+    int farlist[KMAX];      // lines treated through the far field, as byte offsets of their records (fp64: LineRec,
+                            // fp32: linef rows) -- the list is read four times per tile, an index would cost a
+                            // quarter-rate 32-bit multiply each time
 };
 // Taylor tables of the near-axis zone of every line of ONE walker (voigt_math.hpp): 36 KiB, which
 // only a workgroup that serves a single walker can afford (3 workgroups per CU).
@@ -349,11 +351,18 @@ __device__ __forceinline__ void tile_jfrac(const double (&X)[T], const double (&
 
 // sqrt(pi) H from the line's Taylor table, 0 <= x < 8: TAB_NT / 2 16-byte LDS reads + TAB_NT - 1 fused multiply-adds
 __device__ __forceinline__ double table_eval(const double* tab, double x) {
-    const int i = (int)(x * 2.0);
-    const double d = fma((double)i, -vamp::CORE_H, x) - 0.5 * vamp::CORE_H;
+    // interval i = floor(2 x) as round-to-nearest of 2 (x - 1/4): adding 2^52 + 2^51 leaves the integer in the
+    // low word of the sum (no conversions), and on a boundary either neighbour is right (|d| = 1/4 in both)
+    constexpr double MAGIC = 6755399441055744.0;
+    const double xs = x - 0.5 * vamp::CORE_H;
+    const double t = fma(xs, 2.0, MAGIC);
+    const int i = __double2loint(t);
+    const double d = fma(t - MAGIC, -vamp::CORE_H, xs);
+    static_assert(vamp::CORE_H == 0.5, "interval width 1/2");
     static_assert(vamp::TAB_NT % 2 == 0, "coefficient pairs below");
     constexpr int NP = vamp::TAB_NT / 2;
-    const double2* a = reinterpret_cast<const double2*>(tab + i * vamp::TAB_NT);
+    // (v_mad_u32_u24: the 32-bit integer multiply runs at a quarter of the rate)
+    const double2* a = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + __mul24(i, vamp::TAB_NT * (int)sizeof(double)));
     double2 c[NP];
 #pragma unroll
     for (int n = NP - 1; n >= 0; --n) c[n] = a[n];
@@ -585,6 +594,7 @@ __device__ __forceinline__ void ff_eval2(const double (&Xin)[2], const double (&
 //     edge and the whole tile outside |z|^2 < 64 of that line; compacted list -> Sx.farlist
 //     (my_w25: half-width of |z|^2 < 625; far lines that reach into it at the tile's edge need the
 //     deep fractions and are listed first)
+template <int FARLIST_SCALE>       // bytes per line record of the list's readers
 __device__ __forceinline__ unsigned long long ff_classify(TileScratch& Sx, int K, int lane, double my_c, double my_w8,
                                                           double my_w25, double mid, double half) {
     const double dist = fabs(mid - my_c) - half;
@@ -594,7 +604,7 @@ __device__ __forceinline__ unsigned long long ff_classify(TileScratch& Sx, int K
     const unsigned long long below = (1ull << lane) - 1ull;
     if (my_far)
         Sx.farlist[my_deep ? __builtin_popcountll(deepmask & below)
-                           : __builtin_popcountll(deepmask) + __builtin_popcountll(farmask & ~deepmask & below)] = lane;
+                           : __builtin_popcountll(deepmask) + __builtin_popcountll(farmask & ~deepmask & below)] = lane * FARLIST_SCALE;
     return farmask;
 }
 // node sums (lanes 0..15 hold them) -> the four local power series of the tile: lane l = 14 q + j < 56 owns
@@ -633,10 +643,10 @@ __device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileSc
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int q = 4 * t + grp;
-            const int k = Sx.farlist[q < nfar ? q : nfar - 1];
-            X[t] = fabsf(xn - L.linef[k][0]) * L.linef[k][1];
-            yv[t] = L.linef[k][2];
-            av[t] = q < nfar ? L.linef[k][3] : 0.0f;
+            const float* lf = reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.linef) + Sx.farlist[q < nfar ? q : nfar - 1]);
+            X[t] = fabsf(xn - lf[0]) * lf[1];
+            yv[t] = lf[2];
+            av[t] = q < nfar ? lf[3] : 0.0f;
             lo = t ? fminf(lo, X[t] + yv[t]) : X[0] + yv[0];
         }
         float fsf = 0.0f;
@@ -657,10 +667,10 @@ __device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileSc
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int q = 4 * t + grp;
-        const int k = Sx.farlist[q < nfar ? q : nfar - 1];
-        Xn[t] = fabs(xnode - L.line[k].c) * L.line[k].s;
-        yn[t] = L.line[k].y;
-        an[t] = q < nfar ? L.line[k].amp : 0.0;
+        const LineRec& ln = *reinterpret_cast<const LineRec*>(reinterpret_cast<const char*>(L.line) + Sx.farlist[q < nfar ? q : nfar - 1]);
+        Xn[t] = fabs(xnode - ln.c) * ln.s;
+        yn[t] = ln.y;
+        an[t] = q < nfar ? ln.amp : 0.0;
     }
     double fs;
     {
@@ -756,7 +766,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
         const double x_lo = x[base], x_hi = x[base + 64 * T - 1];
 #endif
         const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * fabs(x_hi - x_lo);
-        const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
+        const unsigned long long farmask = ff_classify<(int)sizeof(LineRec)>(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
         // near lines: walk the set bits of the complement of the far mask (1-3 of 16 on the headline)
         // (VAMP_SKIP_*: timing-only builds of tools/variants.py -- the phase split in profiles/)
@@ -901,7 +911,7 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const Wal
         }
         const double x_lo = (double)x[base], x_hi = (double)x[base + 64 * T - 1];
         const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * fabs(x_hi - x_lo);
-        const unsigned long long farmask = ff_classify(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
+        const unsigned long long farmask = ff_classify<4 * (int)sizeof(float)>(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
         for (unsigned long long near = ~farmask & ((1ull << K) - 1ull); near; near &= near - 1ull) {
             const int k = __builtin_ctzll(near);
