@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Developer soak (not collected by pytest): the random long-region comparison of
+tests/test_gpu_parity.py::test_random_long_regions_match_oracle over many more seeds, every packing
+that serves long regions, plus descending and geometrically stretched grids.
+usage (GPU box): python tests/soak_long_regions.py [n_seeds]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import vamp_amd                                   # noqa: E402
+from oracle import vamp_oracle as vo              # noqa: E402
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+worst = {}
+for packing in (0, 64, 256):
+    ctx = vamp_amd.HipContext(device=0)
+    ctx.set_packing(packing)
+    w = 0.0
+    for seed in range(n_seeds):
+        rng = np.random.default_rng(7000 + seed)
+        P = int(rng.choice([512, 768, 1300, 2048, 2560, 4096, 6144]))
+        K = int(rng.integers(1, 17))
+        kind = seed % 4
+        if kind == 0:
+            x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+        elif kind == 1:
+            x = np.cumsum(rng.uniform(0.5, 1.5, P))
+        elif kind == 2:
+            x = np.cumsum(np.geomspace(1.0, 3.0, P))              # spacing grows 3x across the region
+        else:
+            x = -(np.arange(P, dtype=np.float64) - (P - 1) / 2.0) * 0.37       # descending
+        x = x - x.mean()
+        span = abs(x[-1] - x[0])
+        lo, hi = min(x[0], x[-1]), max(x[0], x[-1])
+        W = 8
+        th = np.empty((W, K, 4))
+        th[:, :, 0] = 10.0 ** rng.uniform(-2, 1.7, (W, K))
+        th[:, :, 1] = rng.uniform(lo, hi, (W, K))
+        th[:, :, 2] = 10.0 ** rng.uniform(-6, np.log10(0.4 * span), (W, K))
+        th[:, :, 3] = 10.0 ** rng.uniform(-1.3, np.log10(0.4 * span), (W, K))
+        th = th.reshape(W, 4 * K)
+        noise = np.full(P, 0.05)
+        flux = np.clip(1.0 + rng.normal(0, 0.05, P), 0, None)
+        ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
+        o = np.argsort(x)                        # the oracle restates the reference: ascending grids only
+        r = vo.Region(x=x[o], flux=flux[o], noise=noise[o], n_comp=K, mode=vo.MODE_VOIGT4)
+        want = vo.log_prob_batch_fast(r, th)
+        got = ctx.lnprob(th)
+        assert np.array_equal(np.isfinite(want), np.isfinite(got)), (packing, seed)
+        fin = np.isfinite(want)
+        if fin.any():
+            err = np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))
+            w = max(w, err.max())
+            if err.max() > 1e-9:
+                print("FAIL", packing, seed, P, K, kind, err.max(), flush=True)
+    worst[packing] = w
+    ctx.close()
+    print(f"packing {packing}: worst relative lnprob error over {n_seeds} seeds {w:.3e}", flush=True)
+assert max(worst.values()) <= 1e-9
+print("soak ok")
