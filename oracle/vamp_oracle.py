@@ -27,8 +27,11 @@ Parity pinning: the numpy-only reference statics (``GaussFunction``, ``Chisquare
 ``tests/golden/make_golden.py`` and their outputs are committed as fixtures; this oracle is
 checked against them in ``tests/test_oracle.py``.  Voigt values are pinned by
 ``scipy.special.wofz`` (the north star's named oracle) and spot-checked against mpmath.  The
-reference holds no numeric known-answer for Voigt values, BIC or sampler statistics (astropy,
-pymc absent and unpinned), so for those quantities parity is "unpinned" beyond scipy/mpmath.
+reference holds no numeric known-answer for Voigt values, BIC values or sampler statistics (astropy,
+pymc absent and unpinned), so for those quantities parity is "unpinned" beyond scipy/mpmath.  The
+DEFINITION of the MAP information criteria is pinned by the outputs the reference's
+vpfits_intro.ipynb still holds (BIC - AIC = k (ln n - 2) with k counting `sd`, n = pixels:
+tests/test_notebook_pins.py).
 """
 from __future__ import annotations
 
