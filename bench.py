@@ -275,6 +275,9 @@ def main():
                     help="create the RCCL communicator and run the exchange even with one rank (rehearsal)")
     args = ap.parse_args()
 
+    # the host driver of these boxes only supports dmabuf IPC: without this RCCL's intra-node handles fail
+    # (hipIpcGetMemHandle: invalid argument).  Already exported on the boxes; kept for any other launcher.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "VAMP_BENCH_DEVICE" in os.environ:          # rehearsal knob: several ranks on one GPU (host logic only)

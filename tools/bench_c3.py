@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--packing", type=int, default=0, help="lanes per walker: 0 auto, 16, 64")
     a = ap.parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these boxes
     import vamp_amd
     xs, fs, ns, ks = build_regions()
     rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
