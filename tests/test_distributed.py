@@ -175,7 +175,7 @@ def test_sharded_trajectory_is_rank_independent_cpu(world, tmp_path):
     assert np.array_equal(r["nacc"], nacc)
 
 
-@pytest.mark.parametrize("world,parts,block", [(2, 2, 8), (4, 2, 4), (2, 4, 4)])
+@pytest.mark.parametrize("world,parts,block", [(2, 2, 8), (4, 2, 4), (2, 4, 4), (8, 2, 2)])
 def test_piecewise_exchange_is_rank_independent_cpu(world, parts, block, tmp_path):
     """A rank's share cut into pieces that are stepped and exchanged one after the other (the
     layout behind the overlapped RCCL exchange): same trajectory as the unsharded sampler."""
@@ -188,7 +188,7 @@ def test_piecewise_exchange_is_rank_independent_cpu(world, parts, block, tmp_pat
     assert np.array_equal(r["nacc"], nacc)
 
 
-@pytest.mark.parametrize("world,parts,block", [(2, 1, 8), (2, 2, 4), (4, 2, 4)])
+@pytest.mark.parametrize("world,parts,block", [(2, 1, 8), (2, 2, 4), (4, 2, 4), (8, 1, 4)])
 def test_sharded_host_abi_matches_oracle_cpu(world, parts, block, tmp_path):
     """The walker-sharded driver over gloo with the HOST implementation of the C ABI behind ctypes
     (real set_shard_parts / half_step_part / pack_get / scatter_put calls on every rank): the
