@@ -132,6 +132,10 @@ struct LineRec {           // per (walker, component), lives in LDS
 #define VAMP_PARTS 4
 #endif
 constexpr int PARTS = VAMP_PARTS;
+template <int KCAP, bool OWN_DTAB> struct WalkerLds;
+#ifndef VAMP_SPLIT_WAVES
+#define VAMP_SPLIT_WAVES 4
+#endif
 template <int LPW_, int KCAP_, bool TAIL_, int WPB_, bool SPLIT_ = false, bool TABS_ = SPLIT_, bool FF_ = (LPW_ == 64)>
 struct Pack {
     static constexpr int LPW = LPW_, KCAP = KCAP_, SUBS = 64 / LPW_;
@@ -149,7 +153,12 @@ struct Pack {
     // 9 KB instead of 18 KB of tables per walker, 3 instead of 1.7 wavefronts per SIMD
     static constexpr int LINES_PER_PASS = (SPLIT_ && TABS_ && !FF_ && WPB_ == 1) ? VAMP_BLEND_PASS_LINES : 0;
     static constexpr int TAB_LINES = LINES_PER_PASS > 0 ? LINES_PER_PASS : KCAP_;
-    static constexpr int MIN_WAVES = (SPLIT_ && TABS_ && !FF_ && LINES_PER_PASS == 0) ? 2 : VAMP_MIN_WAVES;
+    // the workgroup-per-walker shape with every line's tables resident needs the near-axis tables (dtab) only
+    // until the Taylor rows are built from them: they live in the tail of the tables' own space (5.6 KB
+    // less LDS: 39.7 KB per workgroup)
+    static constexpr bool DTAB_IN_TABLES = SPLIT_ && TABS_ && FF_;
+    using Lds = WalkerLds<KCAP_, !DTAB_IN_TABLES>;
+    static constexpr int MIN_WAVES = (SPLIT_ && TABS_ && !FF_ && LINES_PER_PASS == 0) ? 2 : DTAB_IN_TABLES ? VAMP_SPLIT_WAVES : VAMP_MIN_WAVES;
     static_assert(!SPLIT_ || (LPW_ == 64 && (WPB_ == PARTS || !FF_) && WPB_ <= PARTS),
                   "a split workgroup is PARTS wavefronts on one walker (tile classes), or up to PARTS wavefronts without far field (contiguous shares)");
 };
@@ -187,11 +196,11 @@ constexpr int FF_NODES = 16;          // Chebyshev nodes of the far-field interp
 constexpr double FF_DIST = VAMP_FF_DIST;   // a line is "far" from a tile when it lies >= FF_DIST half-widths beyond its edge
 #include "ff_matrix.inc"               // FF_M, FF_DEG, FF_ROWS, FF_MAT (tools/gen_ff_matrix.py)
 
-template <int KCAP>
+template <int KCAP, bool OWN_DTAB = true>
 struct WalkerLds {
     double theta[4 * KCAP + 4];
     LineRec line[KCAP];
-    double dtab[KCAP][vamp::DTAB_N];
+    double dtab[OWN_DTAB ? KCAP : 1][vamp::DTAB_N];     // !OWN_DTAB: in the tail of the Taylor tables (Pack::DTAB_IN_TABLES)
     float linef[KCAP][4];  // fp32 path: c, s, y, amp
 };
 struct alignas(16) TileScratch {   // per wavefront: far-field working set of the tile in flight
@@ -209,13 +218,21 @@ struct alignas(16) LineTables { double a[ON ? KCAP * vamp::TAB_LINE : 2]; };
 template <bool F32, int MODE, class PK>
 constexpr bool use_tables() { return PK::TABS && !F32 && MODE != VAMP_GAUSS3; }
 
+// the near-axis table of line k as the evaluators want it (unused by the table look-ups; not addressable
+// through L when it lives in the tables' space)
+template <class PK>
+__device__ __forceinline__ const double* dtab_row(const typename PK::Lds& L, int k) {
+    if constexpr (PK::DTAB_IN_TABLES) return nullptr;
+    else return L.dtab[k];
+}
+
 // barrier over the lanes that stage and sweep one walker together
 template <class PK>
 __device__ __forceinline__ void group_barrier() {
     if constexpr (PK::SPLIT) __syncthreads();
     else __builtin_amdgcn_wave_barrier();
 }
-using WaveLds = WalkerLds<KMAX>;      // the one-walker-per-wavefront kernels (k_model, k_line_records)
+using WaveLds = WalkerLds<KMAX, true>;      // the one-walker-per-wavefront kernels (k_model, k_line_records)
 
 // ---------------------------------------------------------------------------------------
 // wave helpers
@@ -243,7 +260,7 @@ __device__ __forceinline__ double uniform_logp(double v, double lo, double hi, d
 // MODE is a compile-time parameter: one specialised kernel per parameterisation, no mode
 // branches in the staging code or in the pixel loop.
 template <int MODE, class PK = PackWide, bool TAB = false>
-__device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::KCAP>& L, int lane, bool want_f32, int part,
+__device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::Lds& L, int lane, bool want_f32, int part,
                                               double* tab = nullptr) {
     // `lane` is the lane index inside the walker's group (0 .. LPW-1).  In a split workgroup
     // (`part` = wavefront index) all wavefronts evaluate the records and the prior -- each needs
@@ -301,6 +318,11 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
     }
     lp = wave_sum<PK::LPW>(lp);
     group_barrier<PK>();
+    double (*dt)[vamp::DTAB_N];
+    if constexpr (PK::DTAB_IN_TABLES && TAB)
+        dt = reinterpret_cast<double (*)[vamp::DTAB_N]>(tab + PK::KCAP * vamp::TAB_LINE - PK::KCAP * vamp::DTAB_N);
+    else
+        dt = L.dtab;
 #ifdef VAMP_SKIP_DTAB     // timing-only builds (tools/variants.py)
     if (false) {
 #else
@@ -309,7 +331,7 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
         constexpr int STEP = PK::SPLIT ? PK::THREADS : PK::LPW;
         for (int e = PK::SPLIT ? 64 * part + lane : lane; e < K * vamp::DTAB_N; e += STEP) {
             const int k = e / vamp::DTAB_N, n = e % vamp::DTAB_N;
-            L.dtab[k][n] = vamp::core_dtab_entry(n, L.line[k].y);
+            dt[k][n] = vamp::core_dtab_entry(n, L.line[k].y);
         }
     }
     group_barrier<PK>();
@@ -321,10 +343,21 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, WalkerLds<PK::
         // one (line, interval) pair per thread: 16 lines x 16 intervals = the 256 threads of a split
         // group; a single wavefront takes its walker's pairs 64 at a time
         constexpr int TSTEP = PK::SPLIT ? PK::THREADS : PK::LPW;
-        for (int e = PK::SPLIT ? 64 * part + lane : lane; e < K * vamp::TAB_NI; e += TSTEP) {
-            const int k = e / vamp::TAB_NI, i = e % vamp::TAB_NI;
-            vamp::taylor_table_row(i, L.line[k].y, L.dtab[k], L.line[k].pole, L.line[k].hy,
-                                   tab + k * vamp::TAB_LINE + i * vamp::TAB_NT);
+        if constexpr (PK::DTAB_IN_TABLES) {
+            // the near-axis tables occupy the tail of the Taylor tables: every thread reads what its row's centre
+            // needs, and only when all have done so are the rows written (one (line, interval) pair per thread)
+            static_assert(KMAX * vamp::TAB_NI <= PK::THREADS && PK::KCAP * vamp::DTAB_N <= PK::KCAP * vamp::TAB_LINE, "one row per thread");
+            const int e = 64 * part + lane, k = e / vamp::TAB_NI, i = e % vamp::TAB_NI;
+            double c0r = 0.0, c0i = 0.0;
+            if (e < K * vamp::TAB_NI) vamp::core_centre(i, L.line[k].y, dt[k], L.line[k].pole, L.line[k].hy, c0r, c0i);
+            group_barrier<PK>();
+            if (e < K * vamp::TAB_NI) vamp::taylor_table_row_from_centre(i, L.line[k].y, c0r, c0i, tab + k * vamp::TAB_LINE + i * vamp::TAB_NT);
+        } else {
+            for (int e = PK::SPLIT ? 64 * part + lane : lane; e < K * vamp::TAB_NI; e += TSTEP) {
+                const int k = e / vamp::TAB_NI, i = e % vamp::TAB_NI;
+                vamp::taylor_table_row(i, L.line[k].y, dt[k], L.line[k].pole, L.line[k].hy,
+                                       tab + k * vamp::TAB_LINE + i * vamp::TAB_NT);
+            }
         }
         group_barrier<PK>();
     }
@@ -378,7 +411,9 @@ __device__ __forceinline__ double table_eval(const double* tab, double x) {
 // `tab` (TAB = true): the line's Taylor table replaces the near-axis rule for |z|^2 < 64
 template <int T, bool TAB = false>
 __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab, const double (&Xin)[T], double (&H)[T],
-                                           const double* tab = nullptr) {
+                                           const double* tab = nullptr, const double* ec = nullptr) {
+    // ec: the exp constants in LDS (tile kernels with the far-field table) or null (literals)
+    auto gauss_tail = [ec](double xx) { return ec ? vamp::exp_neg_sq_tab(xx, ec) : vamp::exp_neg_sq(xx); };
     const double y = ln.y;
     const double y2 = y * y;
     // narrow line: |z| spans many units (possibly decades) inside one tile, and a lane promoted to a
@@ -427,13 +462,13 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
                 if (y < vamp::Y_TINY) {
 #pragma unroll
                     for (int t = 0; t < T; ++t)
-                        if (!(r2[t] < vamp::R2_CORE)) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
+                        if (!(r2[t] < vamp::R2_CORE)) H[t] += vamp::SQRT_PI * gauss_tail(X[t]);
                 }
             } else {
                 tile_jfrac<6, T>(X, r2, y, H);
                 if (y < vamp::Y_TINY) {
 #pragma unroll
-                    for (int t = 0; t < T; ++t) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
+                    for (int t = 0; t < T; ++t) H[t] += vamp::SQRT_PI * gauss_tail(X[t]);
                 }
             }
         } else {
@@ -460,7 +495,7 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
 // chains and one LDS read of the line record per TPIX evaluations; the remaining pixels of the
 // region run one per lane.
 template <int MODE, class PK, int T, bool TAB = false>
-__device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x,
+__device__ __forceinline__ void sweep_range(const RegionDev& R, const typename PK::Lds& L, const double* __restrict__ x,
                                             const double* __restrict__ f, const double* __restrict__ wt, int lane,
                                             int base0, int base1, int stride, double& chi, const double* tab = nullptr) {
     const int K = R.K, P = R.P;
@@ -502,7 +537,7 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<
                 double X[T], H[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t) X[t] = fabs(xi[t] - ln.c) * ln.s;
-                tile_voigt<T, TAB>(ln, L.dtab[k], X, H, TAB ? tab + k * vamp::TAB_LINE : nullptr);
+                tile_voigt<T, TAB>(ln, dtab_row<PK>(L, k), X, H, TAB ? tab + k * vamp::TAB_LINE : nullptr);
 #pragma unroll
                 for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
             }
@@ -539,11 +574,13 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const WalkerLds<
 //      instructions per far line.
 // On the headline workload ~90 % of the (pixel, line) evaluations are far: 64 wave-evaluations
 // per tile shrink to ~6 direct ones + ~4 at the nodes.
-constexpr int FF_TABLE = FF_MAT + FF_NODES;   // the matrix [n/2][lane][n%2] followed by the node abscissae
+constexpr int FF_EXP = FF_MAT + FF_NODES;     // constants of the exp kernel (vamp::exp_taylor_tab), 16-byte aligned
+constexpr int FF_TABLE = FF_EXP + vamp::EXP_TAB_N;   // the matrix [n/2][lane][n%2], the node abscissae, the exp constants
+__device__ const double EXP_TAB[vamp::EXP_TAB_N] = VAMP_EXP_TAB_INIT;
 
 // every thread of the workgroup copies its share; call before any thread can leave the kernel
 __device__ __forceinline__ void ff_fill_table(double* dct) {
-    for (int e = threadIdx.x; e < FF_TABLE; e += blockDim.x) dct[e] = FF_M[e];
+    for (int e = threadIdx.x; e < FF_TABLE; e += blockDim.x) dct[e] = e < FF_EXP ? FF_M[e] : EXP_TAB[e - FF_EXP];
     __syncthreads();
 }
 
@@ -561,7 +598,7 @@ __device__ __forceinline__ void ff_frac2(const double (&X)[2], const double (&y)
     H[1] = n[1] * (ra * d[0]);
 }
 
-__device__ __forceinline__ void ff_eval2(const double (&Xin)[2], const double (&y)[2], double (&H)[2]) {
+__device__ __forceinline__ void ff_eval2(const double (&Xin)[2], const double (&y)[2], double (&H)[2], const double* ec) {
     double X[2], r2[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -585,7 +622,7 @@ __device__ __forceinline__ void ff_eval2(const double (&Xin)[2], const double (&
     if (__any(ymin < vamp::Y_TINY)) {           // the fractions miss e^{-x^2}; it matters for y < ~1e-11 near |z| = 8
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-            if (y[t] < vamp::Y_TINY) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq(X[t]);
+            if (y[t] < vamp::Y_TINY) H[t] += vamp::SQRT_PI * vamp::exp_neg_sq_tab(X[t], ec);
     }
 }
 
@@ -629,8 +666,8 @@ __device__ __forceinline__ void ff_series(TileScratch& Sx, const double* __restr
 // (b) optical depth of the far lines at the tile's Chebyshev nodes -> the tile's local power series in Sx.coef
 //     W4NODES (fp32 contexts): node values through Humlicek's W4 in fp32 -- every far point has
 //     |x| + y >= 8, so region II (or I, wave-uniform) applies; transform and coefficients stay fp64
-template <int KCAP, bool W4NODES = false>
-__device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
+template <class LDS, bool W4NODES = false>
+__device__ __forceinline__ void ff_coefficients(const LDS& L, TileScratch& Sx, const double* __restrict__ dct,
                                                 int lane, int nfar, double mid, double half) {
     const int node = lane & (FF_NODES - 1), grp = lane >> 4;
     const double tnode = dct[FF_MAT + node];                       // cos(pi (node + 1/2) / 16)
@@ -676,13 +713,13 @@ __device__ __forceinline__ void ff_coefficients(const WalkerLds<KCAP>& L, TileSc
     {
         const double Xa[2] = {Xn[0], Xn[1]}, ya[2] = {yn[0], yn[1]};
         double Ha[2];
-        ff_eval2(Xa, ya, Ha);
+        ff_eval2(Xa, ya, Ha, dct + FF_EXP);
         fs = fma(an[0], Ha[0], an[1] * Ha[1]);
     }
     if (nfar > 8) {                               // list entries 8..15 (slots 2, 3)
         const double Xb[2] = {Xn[2], Xn[3]}, yb[2] = {yn[2], yn[3]};
         double Hb[2];
-        ff_eval2(Xb, yb, Hb);
+        ff_eval2(Xb, yb, Hb, dct + FF_EXP);
         fs += fma(an[2], Hb[0], an[3] * Hb[1]);
     }
     fs += __shfl_xor(fs, 16, 64);
@@ -716,7 +753,7 @@ __device__ __forceinline__ void ff_horner(const TileScratch& Sx, const real (&xi
 }
 
 template <int MODE, class PK, bool TAB>
-__device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
+__device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const typename PK::Lds& L, TileScratch& Sx, const double* __restrict__ dct,
                                                const double* __restrict__ x, const double* __restrict__ f,
                                                const double* __restrict__ wt, int lane, int base0, int base1, int stride,
                                                double& chi, const double* tab) {
@@ -777,7 +814,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
             double X[T], H[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) X[t] = fabs(xi[t] - ln.c) * ln.s;
-            tile_voigt<T, TAB>(ln, L.dtab[k], X, H, TAB ? tab + k * vamp::TAB_LINE : nullptr);
+            tile_voigt<T, TAB>(ln, dtab_row<PK>(L, k), X, H, TAB ? tab + k * vamp::TAB_LINE : nullptr, dct + FF_EXP);
 #pragma unroll
             for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
         }
@@ -787,7 +824,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
         // load to its use and the wavefront sits through eight L2 round trips per tile
         double fi[T], wi[T];
 #ifndef VAMP_SKIP_FFNODES
-        if (nfar > 0) ff_coefficients(L, Sx, dct, lane, nfar, mid, half);
+        if (nfar > 0) ff_coefficients<typename PK::Lds>(L, Sx, dct, lane, nfar, mid, half);
 #endif
 #if VAMP_EARLY_LOADS
 #pragma unroll
@@ -800,6 +837,11 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
 #ifndef VAMP_SKIP_CLENSHAW
         if (nfar > 0) ff_horner<double, T>(Sx, xi, mid, half, x_hi > x_lo, tau);
 #endif
+        // the exp constants are read from LDS here, per tile: as literals they sit in ~30 SGPRs (or VGPRs) through
+        // the whole loop, and the pointers and masks they displace are then reloaded from VGPR lanes in every tile
+        int eoff = FF_EXP;
+        asm volatile("" : "+s"(eoff));          // (keeps the compiler from hoisting the reads out of the loop)
+        const double* ec = dct + eoff;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
 #if !VAMP_EARLY_LOADS
@@ -809,7 +851,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const WalkerL
 #ifdef VAMP_SKIP_EXP
             const double m = 1.0 - tau[t];
 #else
-            const double m = vamp::exp_taylor(-tau[t]);
+            const double m = vamp::exp_taylor_tab(-tau[t], ec);
 #endif
             const double r = (fi[t] - m) * wi[t];
             chi = fma(r, r, chi);
@@ -844,7 +886,7 @@ __device__ __forceinline__ void tile_w4(float y, const float (&X)[T], float (&H)
 }
 
 template <int MODE, class PK, int T>
-__device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const float* __restrict__ x,
+__device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const typename PK::Lds& L, const float* __restrict__ x,
                                                 const float* __restrict__ f, const float* __restrict__ wt, int lane,
                                                 int base0, int base1, int stride, double& chi) {
     const int K = R.K, P = R.P;
@@ -891,7 +933,7 @@ __device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const Walker
 // the tile's interpolant -- node values and cosine transform in fp64 (one evaluation per lane,
 // same code as the fp64 path), transform in fp64, Horner per pixel in fp32.
 template <int MODE, class PK>
-__device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx,
+__device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const typename PK::Lds& L, TileScratch& Sx,
                                                    const double* __restrict__ dct, const float* __restrict__ x,
                                                    const float* __restrict__ f, const float* __restrict__ wt, int lane,
                                                    int base0, int base1, int stride, double& chi) {
@@ -924,7 +966,7 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const Wal
             for (int t = 0; t < T; ++t) tau[t] = fmaf(a, H[t], tau[t]);
         }
         if (nfar > 0) {
-            ff_coefficients<PK::KCAP, true>(L, Sx, dct, lane, nfar, mid, half);
+            ff_coefficients<typename PK::Lds, true>(L, Sx, dct, lane, nfar, mid, half);
             ff_horner<float, T>(Sx, xi, mid, half, x_hi > x_lo, tau);
         }
 #pragma unroll
@@ -948,7 +990,7 @@ struct PixPtrs {
 // or through `red` by the PARTS wavefronts of the workgroup (SPLIT = true, `part` = this wave's
 // class): the same order of additions either way.  The tail (pixels beyond the last full tile) belongs to class 0.
 template <bool F32, int MODE, class PK, bool TAB = use_tables<F32, MODE, PK>()>
-__device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
+__device__ __forceinline__ void sweep_class(const RegionDev& R, const typename PK::Lds& L, TileScratch& Sx, const double* __restrict__ dct,
                                             const PixPtrs& px, int lane, int base0, int full, int stride, bool tail, double& chi,
                                             const double* tab) {
     if constexpr (F32) {
@@ -996,7 +1038,7 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const WalkerLds<
 // ---- blends: tables of a few lines at a time, optical depths in registers across the passes -------
 // T pixels per lane (base + 64 t + lane) of lines k0 .. k0 + kn - 1, whose tables sit in `tab`
 template <int MODE, class PK, int T>
-__device__ __forceinline__ void blend_chunk(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x, int lane,
+__device__ __forceinline__ void blend_chunk(const RegionDev& R, const typename PK::Lds& L, const double* __restrict__ x, int lane,
                                             int base, int k0, int kn, const double* tab, double (&tau)[4]) {
     double xi[T];
 #pragma unroll
@@ -1015,7 +1057,7 @@ __device__ __forceinline__ void blend_chunk(const RegionDev& R, const WalkerLds<
     }
 }
 template <int MODE, class PK>
-__device__ __forceinline__ void blend_chunk_n(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const double* __restrict__ x, int lane,
+__device__ __forceinline__ void blend_chunk_n(const RegionDev& R, const typename PK::Lds& L, const double* __restrict__ x, int lane,
                                               int base, int tn, int k0, int kn, const double* tab, double (&tau)[4]) {
     if (tn >= 4) blend_chunk<MODE, PK, 4>(R, L, x, lane, base, k0, kn, tab, tau);
     else if (tn == 3) blend_chunk<MODE, PK, 3>(R, L, x, lane, base, k0, kn, tab, tau);
@@ -1024,7 +1066,7 @@ __device__ __forceinline__ void blend_chunk_n(const RegionDev& R, const WalkerLd
 }
 constexpr int BLEND_MAX_PIXELS = 512;     // two chunks of up to 4 pixels per lane
 template <int MODE, class PK>
-__device__ __forceinline__ double sweep_blend_passes(const RegionDev& R, const WalkerLds<PK::KCAP>& L, const PixPtrs& px, int lane,
+__device__ __forceinline__ double sweep_blend_passes(const RegionDev& R, const typename PK::Lds& L, const PixPtrs& px, int lane,
                                                      double* tab) {
     static_assert(PK::WPB == 1 && PK::LPW == 64, "one wavefront per walker");
     constexpr int LP = PK::LINES_PER_PASS;
@@ -1065,7 +1107,7 @@ __device__ __forceinline__ double sweep_blend_passes(const RegionDev& R, const W
 }
 
 template <bool F32, int MODE, class PK = PackWide>
-__device__ __forceinline__ double sweep_pixels(const RegionDev& R, const WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* __restrict__ dct,
+__device__ __forceinline__ double sweep_pixels(const RegionDev& R, const typename PK::Lds& L, TileScratch& Sx, const double* __restrict__ dct,
                                                const PixPtrs& px, int lane, int part, double* red, const double* tab) {
     constexpr int TILE = PK::LPW * TPIX;
     const int full = (R.P / TILE) * TILE;
@@ -1133,7 +1175,7 @@ __device__ __forceinline__ double loglike_from_sum(const RegionDev& R, const LDS
 // group.  Groups of one wave may leave early independently: everything below communicates only
 // inside a group (xor shuffles with offsets < LPW) or through __any, which ignores inactive lanes.
 template <bool F32, int MODE, class PK = PackWide>
-__device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::KCAP>& L, TileScratch& Sx, const double* dct,
+__device__ __forceinline__ double wave_lnprob(const RegionDev& R, typename PK::Lds& L, TileScratch& Sx, const double* dct,
                                               const PixPtrs& px, int lane, double* chi_out, int part, double* red, double* tab) {
     const double lp = stage_lines<MODE, PK, use_tables<F32, MODE, PK>() && PK::LINES_PER_PASS == 0>(R, L, lane, F32, part, tab);
     if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
@@ -1141,7 +1183,7 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, WalkerLds<PK::
         return NEG_INF;
     }
 #ifdef VAMP_SKIP_SWEEP    // timing-only builds (tools/variants.py)
-    const double ssum = L.line[0].y + L.dtab[0][lane & 31] + (tab ? tab[lane] : 0.0);
+    const double ssum = L.line[0].y + L.theta[lane & 31] + (tab ? tab[lane] : 0.0);
 #else
     const double ssum = sweep_pixels<F32, MODE, PK>(R, L, Sx, dct, px, lane, part, red, tab);
 #endif
@@ -1164,7 +1206,7 @@ __global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_lnprob(const Reg
     // (block r starts at W * d_before(r)), lnprob / chi2 are [n_regions, W]
     const bool all = region < 0;
     if (all) region = region_list ? region_list[blockIdx.y] : (int)blockIdx.y;
-    __shared__ WalkerLds<PK::KCAP> lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
+    __shared__ typename PK::Lds lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
     __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
     __shared__ alignas(16) double dct[PK::FF ? FF_TABLE : 1];
     __shared__ double red[PARTS];
@@ -1180,7 +1222,7 @@ __global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_lnprob(const Reg
         lnprob += (long long)region * W;
         if (chi2) chi2 += (long long)region * W;
     }
-    WalkerLds<PK::KCAP>& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
+    typename PK::Lds& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
     if (!PK::SPLIT || wave == 0)
         for (int d = l; d < R.D; d += PK::LPW) L.theta[d] = theta[w * R.D + d];
     group_barrier<PK>();
@@ -1395,7 +1437,7 @@ __global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_half_step(Sample
                                                      const int* __restrict__ ext_partner, const double* __restrict__ ext_z,
                                                      const double* __restrict__ ext_logu, const double* __restrict__ ext_logz) {
     constexpr bool EXT = DRAWS == DRAW_HOST;
-    __shared__ WalkerLds<PK::KCAP> lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
+    __shared__ typename PK::Lds lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
     __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
     __shared__ alignas(16) double dct[PK::FF ? FF_TABLE : 1];
     __shared__ double red[PARTS];
@@ -1433,7 +1475,7 @@ __global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_half_step(Sample
         }
     }
     const RegionDev R = S.regions[region];
-    WalkerLds<PK::KCAP>& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
+    typename PK::Lds& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
 #ifdef VAMP_ROWS_CACHED    // timing-only builds: every row read hits a 64-row window (no HBM latency)
     double* Xs = S.X + R.theta_off + (ws & 63) * R.D;
     const double* Xc = S.X + R.theta_off + (wc & 63) * R.D;

@@ -110,6 +110,30 @@ VAMP_DEV double exp_taylor(double a) {
     return ldexp(p, (int)n);                                   // NaN in: n = NaN -> p = NaN out
 }
 
+// The same with its 15 constants read from a table (EXP_TAB below, copied to LDS by the tile kernels):
+// fp64 literals occupy SGPR (or VGPR) pairs for the whole pixel loop, these are read where they are used
+// and gone again.  Same operations on the same constants: bit-identical to exp_taylor.
+constexpr int EXP_TAB_N = 16;
+#define VAMP_EXP_TAB_INIT {1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10, vamp::F13, vamp::F12, \
+                           vamp::F11, vamp::F10, vamp::F9, vamp::F8, vamp::F7, vamp::F6, vamp::F5, vamp::F4, vamp::F3, vamp::F2, 0.0}
+VAMP_DEV double exp_taylor_tab(double a, const double* c) {
+    a = (a < -800.0) ? -800.0 : a;
+    const double n = rint(a * c[0]);
+    double r = fma(-n, c[1], a);
+    r = fma(-n, c[2], r);
+    double p = c[3];
+#pragma unroll
+    for (int k = 4; k <= 14; ++k) p = fma(p, r, c[k]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+VAMP_DEV double exp_neg_sq_tab(double x, const double* c) {
+    double s = x * x;
+    double e = fma(x, x, -s);
+    return exp_taylor_tab(-s, c) * (1.0 - e);
+}
+
 // exp(-x^2) with the rounding error of x*x folded back in (x up to ~27 before underflow matters)
 VAMP_DEV double exp_neg_sq(double x) {
     double s = x * x;
@@ -441,14 +465,8 @@ VAMP_DEV void core_centre(int i, double y, const double* dtab, double pole, doub
     }
 }
 
-// the TAB_NT coefficients of interval i, written to out[0 .. TAB_NT)
-VAMP_DEV void taylor_table_row(int i, double y, const double* dtab, double pole, double hy, double* out) {
-    double c0r, c0i;
-#ifdef VAMP_TT_NOCENTRE     // timing-only builds (tools/variants.py)
-    c0r = hy + dtab[i]; c0i = pole;
-#else
-    core_centre(i, y, dtab, pole, hy, c0r, c0i);
-#endif
+// the TAB_NT coefficients of interval i from sqrt(pi) w at its centre, written to out[0 .. TAB_NT)
+VAMP_DEV void taylor_table_row_from_centre(int i, double y, double c0r, double c0i, double* out) {
     const double zr = (i + 0.5) * CORE_H, zi = y;
     // c_1 = -2 z c_0 + 2i
     double c1r = -2.0 * (zr * c0r - zi * c0i);
@@ -485,6 +503,17 @@ VAMP_DEV void taylor_table_row(int i, double y, const double* dtab, double pole,
 #pragma unroll
     for (int n = 0; n < TAB_NT; ++n) out[n] = cr[n];
 #endif
+}
+
+// the same from the line's near-axis table
+VAMP_DEV void taylor_table_row(int i, double y, const double* dtab, double pole, double hy, double* out) {
+    double c0r, c0i;
+#ifdef VAMP_TT_NOCENTRE     // timing-only builds (tools/variants.py)
+    c0r = hy + dtab[i]; c0i = pole;
+#else
+    core_centre(i, y, dtab, pole, hy, c0r, c0i);
+#endif
+    taylor_table_row_from_centre(i, y, c0r, c0i, out);
 }
 
 // sqrt(pi) H(x, y) for 0 <= x < 8 from the line's table
