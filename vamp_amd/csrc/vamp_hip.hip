@@ -114,6 +114,7 @@ struct LineRec {           // per (walker, component), lives in LDS
     double pole;           // core_pole_factor(y)
     double hy;             // core_hy(y)
     double xcap;           // +inf, or X_FAR when one tile of pixels spans > 16 units of |z| (narrow line)
+    double w8, w25;        // half-widths, in x, of |z|^2 < 64 and |z|^2 < 625 around the centre (far-field classification)
 };
 
 // Packing of walkers onto wavefronts.  LPW lanes serve one walker (SUBS = 64/LPW walkers share a
@@ -292,6 +293,7 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
         rec.c = c;
         if constexpr (MODE == VAMP_GAUSS3) {
             rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0; rec.hy = 0.0; rec.xcap = __builtin_huge_val();
+            rec.w8 = rec.w25 = 0.0;
         } else {
             const double rG = vamp::rcp_nr(G);          // one reciprocal for both scales (G = 0 -> inf -> rejected below)
             rec.s = (2.0 * SQRT_LN2) * rG;
@@ -302,6 +304,12 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
             // packed waves: another walker of the wave may force a deep fraction on this one, so every
             // line is capped there
             rec.xcap = (PK::SUBS == 1 && rec.s * R.tile_span <= 16.0) ? __builtin_huge_val() : vamp::X_FAR;   // NaN -> capped
+            if constexpr (PK::FF) {
+                rec.w8 = sqrt(fmax(vamp::R2_CORE - rec.y * rec.y, 0.0)) / rec.s;
+                rec.w25 = sqrt(fmax(vamp::R2_M3 - rec.y * rec.y, 0.0)) / rec.s;
+            } else {
+                rec.w8 = rec.w25 = 0.0;
+            }
             // a degenerate width (G = 0 or non-finite scale) makes the reference's profile NaN, which
             // its sampler rejects; reject here, before the sweep
             if (!(rec.s < __builtin_huge_val()) || !(rec.y < __builtin_huge_val())) lp = NEG_INF;
@@ -761,10 +769,9 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const typenam
     static_assert(PK::LPW == 64 && PK::KCAP <= 16, "far-field tiles: one walker per wavefront, <= 16 lines");
     const int K = R.K;
     // lane k < K classifies line k; w8 = half-width of |z|^2 < 64 around the line centre, in x units
+    // (centre and zone half-widths of "its" line are read from the record in every tile: three LDS reads
+    // instead of six registers held through the loop; the opaque index keeps the reads in the loop)
     const int kk = lane < K ? lane : 0;
-    const double my_c = L.line[kk].c;
-    const double my_w8 = sqrt(fmax(vamp::R2_CORE - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
-    const double my_w25 = sqrt(fmax(vamp::R2_M3 - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
 #if VAMP_X_PREFETCH
     // the abscissae of a tile are requested one tile ahead: they head every dependency chain of the
     // tile (classification, near lines, far-field series), and an L2 round trip at the top of each of the
@@ -803,7 +810,10 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const typenam
         const double x_lo = x[base], x_hi = x[base + 64 * T - 1];
 #endif
         const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * fabs(x_hi - x_lo);
-        const unsigned long long farmask = ff_classify<(int)sizeof(LineRec)>(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
+        int kq = kk;
+        asm volatile("" : "+v"(kq));
+        const LineRec& me = L.line[kq];
+        const unsigned long long farmask = ff_classify<(int)sizeof(LineRec)>(Sx, K, lane, me.c, me.w8, me.w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
         // near lines: walk the set bits of the complement of the far mask (1-3 of 16 on the headline)
         // (VAMP_SKIP_*: timing-only builds of tools/variants.py -- the phase split in profiles/)
@@ -941,9 +951,6 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const typ
     static_assert(PK::LPW == 64 && PK::KCAP <= 16 && MODE != VAMP_GAUSS3, "far-field tiles: one walker per wavefront, Voigt lines");
     const int K = R.K;
     const int kk = lane < K ? lane : 0;
-    const double my_c = L.line[kk].c;
-    const double my_w8 = sqrt(fmax(vamp::R2_CORE - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
-    const double my_w25 = sqrt(fmax(vamp::R2_M3 - L.line[kk].y * L.line[kk].y, 0.0)) / L.line[kk].s;
     for (int base = base0; base < base1; base += stride) {
         float xi[T], tau[T];
 #pragma unroll
@@ -953,7 +960,10 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const typ
         }
         const double x_lo = (double)x[base], x_hi = (double)x[base + 64 * T - 1];
         const double mid = 0.5 * (x_lo + x_hi), half = 0.5 * fabs(x_hi - x_lo);
-        const unsigned long long farmask = ff_classify<4 * (int)sizeof(float)>(Sx, K, lane, my_c, my_w8, my_w25, mid, half);
+        int kq = kk;
+        asm volatile("" : "+v"(kq));
+        const LineRec& me = L.line[kq];
+        const unsigned long long farmask = ff_classify<4 * (int)sizeof(float)>(Sx, K, lane, me.c, me.w8, me.w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
         for (unsigned long long near = ~farmask & ((1ull << K) - 1ull); near; near &= near - 1ull) {
             const int k = __builtin_ctzll(near);
