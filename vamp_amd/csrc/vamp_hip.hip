@@ -56,6 +56,7 @@
 #ifndef VAMP_X_PREFETCH
 #define VAMP_X_PREFETCH 0
 #endif
+
 #ifndef VAMP_MIN_WAVES
 #define VAMP_MIN_WAVES 3
 #endif
@@ -430,8 +431,13 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
     // below.  One v_min per evaluation; the patch is a wave-uniform branch.
     const double xcap = ln.xcap;
     double X[T];
+    if (xcap < __builtin_huge_val()) {           // (wave-uniform: four v_min less per line and tile for ordinary lines)
 #pragma unroll
-    for (int t = 0; t < T; ++t) X[t] = fmin(Xin[t], xcap);
+        for (int t = 0; t < T; ++t) X[t] = fmin(Xin[t], xcap);
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) X[t] = Xin[t];
+    }
     double r2[T];
     double lo;
 #pragma unroll
