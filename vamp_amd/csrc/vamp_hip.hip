@@ -148,8 +148,9 @@ struct Pack {
     static constexpr int WPB = WPB_;        // wavefronts per workgroup
     static constexpr int THREADS = 64 * WPB_;
     static constexpr int WALKERS_PER_BLOCK = SPLIT_ ? 1 : WPB_ * SUBS;
-    // wavefronts per SIMD the register allocation aims for: 3 (<= 168 VGPRs) everywhere except the
-    // blend shape, whose 22 KB of LDS per single-wave workgroup allow fewer than 2 anyway
+    // wavefronts per SIMD the register allocation aims for (MIN_WAVES below): 3 (<= 168 VGPRs), 4 (128 VGPRs,
+    // 40 KB of LDS) for the workgroup-per-walker shape with the far field, 2 for a blend shape with every
+    // line's tables resident
     // the blend shape keeps the Taylor tables of only LINES_PER_PASS lines in LDS at a time (0: of all
     // KCAP lines) and sweeps its pixels once per pass with the optical depths held in registers:
     // 9 KB instead of 18 KB of tables per walker, 3 instead of 1.7 wavefronts per SIMD
@@ -213,8 +214,8 @@ struct alignas(16) TileScratch {   // per wavefront: far-field working set of th
                             // fp32: linef rows) -- the list is read four times per tile, an index would cost a
                             // quarter-rate 32-bit multiply each time
 };
-// Taylor tables of the near-axis zone of every line of ONE walker (voigt_math.hpp): 36 KiB, which
-// only a workgroup that serves a single walker can afford (3 workgroups per CU).
+// Taylor tables of the near-axis zone of every line of ONE walker (voigt_math.hpp): 28 KiB, which
+// only a workgroup that serves a single walker can afford (4 workgroups per CU).
 template <bool ON, int KCAP = KMAX>
 struct alignas(16) LineTables { double a[ON ? KCAP * vamp::TAB_LINE : 2]; };
 template <bool F32, int MODE, class PK>
@@ -1444,8 +1445,8 @@ __global__ __launch_bounds__(256) void k_draws(SamplerDev S, unsigned step, int 
 // One half-step of the stretch move, one wavefront per active walker.
 //   DRAWS = DRAW_INLINE: Philox in-kernel; DRAW_HOST: every draw supplied by the host for ONE region
 //   (deterministic-parity hook); DRAW_PRE: read from the arrays k_draws filled for this launch.
-// 3 waves per SIMD (<= 168 VGPRs): the far-field path is latency-bound in places (LDS round trips);
-// measured 6.94 -> 6.49 ms against the allocator's unconstrained 182 VGPRs / 2 waves
+// Wavefronts per SIMD are set per shape (Pack::MIN_WAVES): the tile code is latency-bound in places (LDS and
+// scalar-cache round trips); the headline shape measured 4.29 / 3.46 / 3.28 ms at 2 / 3 / 4 of them
 constexpr int DRAW_INLINE = 0, DRAW_HOST = 1, DRAW_PRE = 2;
 template <bool F32, int DRAWS, int MODE, class PK>
 __global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
