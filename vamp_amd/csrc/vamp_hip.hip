@@ -1570,9 +1570,11 @@ int fail(int code, const std::string& msg) {
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
+        if (e_ != hipSuccess) {                                                               \
+            (void)hipGetLastError();   /* reported here: do not leave it for the next library (RCCL) to find */ \
             return fail(e_ == hipErrorOutOfMemory ? VAMP_ERR_NOMEM : VAMP_ERR_HIP,            \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+        }                                                                                     \
     } while (0)
 
 // device allocation released on every exit path of a host function
@@ -1927,11 +1929,29 @@ int rccl_api(RcclApi** out) {
         // which lets two ranks share the one GPU of a test box -- RCCL itself refuses that -- and runs the
         // whole in-library exchange path at world > 1.
         if (const char* over = getenv("VAMP_RCCL_LIB")) h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
-        if (!h)
-            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) {
+            // RCCL must sit on the SAME HIP / HSA runtime as this library: a process that also imports torch holds
+            // torch's private copies (torch/lib/libamdhip64.so, libhsa-runtime64.so, librccl.so) beside the system
+            // ones, and an RCCL bound to a runtime nobody initialised fails in ncclCommInitRank ("no ROCm-capable
+            // device is detected") -- which copy a bare dlopen("librccl.so") returns depends on the import order.
+            // So: first the librccl next to the libamdhip64 this library is linked against, then the usual names.
+            std::vector<std::string> names;
+            Dl_info info;
+            if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+                std::string dir(info.dli_fname);
+                const size_t cut = dir.rfind('/');
+                if (cut != std::string::npos) {
+                    dir.resize(cut);
+                    names.push_back(dir + "/librccl.so.1");
+                    names.push_back(dir + "/librccl.so");
+                }
+            }
+            for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) names.push_back(n);
+            for (const std::string& name : names) {
+                h = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
                 if (h) break;
             }
+        }
         if (h) {
             api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
             api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
@@ -2725,6 +2745,9 @@ int vamp_comm_init_rank(vamp_ctx* c, const char* id, int rank, int world) {
     int rc = rccl_api(&api);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    // RCCL checks the runtime's sticky last error during initialisation: one left behind by an earlier call of
+    // anyone in this process (a failed allocation, a rejected argument) would surface as "unhandled cuda error"
+    (void)hipGetLastError();
     RcclUniqueId u;
     std::memcpy(u.internal, id, VAMP_COMM_ID_BYTES);
     void* comm = nullptr;
