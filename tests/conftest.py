@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:        # torch first, whatever the test order: its wheel carries private copies of the ROCm runtime, and a process
+    import torch  # noqa: F401  that loads libvamp_hip.so BEFORE torch ends up with two runtimes
+except Exception:       # noqa: BLE001  (CPU-only tests do not need it)
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
