@@ -266,14 +266,17 @@ template <int MODE, class PK = PackWide, bool TAB = false>
 __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::Lds& L, int lane, bool want_f32, int part,
                                               double* tab = nullptr) {
     // `lane` is the lane index inside the walker's group (0 .. LPW-1).  In a split workgroup
-    // (`part` = wavefront index) all wavefronts evaluate the records and the prior -- each needs
-    // the prior to decide whether to sweep -- the first one stores them, and the per-line tables
-    // are filled by all 256 threads.
+    // (`part` = wavefront index) the FIRST wavefront evaluates the records and the prior and leaves the
+    // prior in a spare slot of the parameter block for the others (each needs it to decide whether to
+    // sweep); the per-line tables are filled by all 256 threads.  (All four used to evaluate them: the
+    // kernel is bound by VALU throughput, and the staging -- divisions, square roots, a logarithm per
+    // line -- was 3 % of its instructions three times over.)
     const bool writer = !PK::SPLIT || part == 0;
+    constexpr int LP_SLOT = 4 * PK::KCAP + 3;       // theta holds at most 4 KCAP + 1 parameters
     double lp = 0.0;
     const int K = R.K;
     constexpr int Q = (MODE == VAMP_VOIGT4) ? 4 : 3;
-    if (lane < K) {
+    if (lane < K && writer) {
         const double* t = &L.theta[Q * lane];
         double a, c, Lw = 0.0, G = 0.0, sg = 0.0;
         if constexpr (MODE == VAMP_GAUSS3) {
@@ -323,11 +326,15 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
             L.linef[lane][3] = (float)(MODE == VAMP_GAUSS3 ? rec.amp : rec.amp * SQRT_PI);   // W4 returns H itself
         }
     }
-    if (R.sample_sd && lane == PK::KCAP) {      // one otherwise idle lane: sd ~ U(0,1), vpfits.py:39
+    if (R.sample_sd && lane == PK::KCAP && writer) {      // one otherwise idle lane: sd ~ U(0,1), vpfits.py:39
         lp = uniform_logp(L.theta[R.D - 1], 0.0, 1.0, 0.0);
     }
     lp = wave_sum<PK::LPW>(lp);
+    if constexpr (PK::SPLIT) {
+        if (writer && lane == 0) L.theta[LP_SLOT] = lp;
+    }
     group_barrier<PK>();
+    if constexpr (PK::SPLIT) lp = L.theta[LP_SLOT];
     double (*dt)[vamp::DTAB_N];
     if constexpr (PK::DTAB_IN_TABLES && TAB)
         dt = reinterpret_cast<double (*)[vamp::DTAB_N]>(tab + PK::KCAP * vamp::TAB_LINE - PK::KCAP * vamp::DTAB_N);
