@@ -2,7 +2,12 @@
 """Headline benchmark: walker-steps/s of the stretch-move + Voigt log-posterior hot path on the
 synthetic 16 384-pixel x 16-component x 65 536-walker region of BASELINE.json (config 4).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+every rank finds RANK / LOCAL_RANK / WORLD_SIZE in its environment.  Started plainly (`python bench.py
+--gpus N`, no WORLD_SIZE) this process touches no GPU: it starts that same launcher as a CHILD process,
+relays rank 0's JSON line and exits with the child's code.
 
 A "step" is one full stretch-move step of the whole ensemble (two half-steps: every walker gets
 one proposal, one log-posterior evaluation and one accept/reject).  Inputs (spectrum, initial
@@ -41,20 +46,26 @@ def _voigt_tau(x, A, c, L, G):
     return A * L * np.sqrt(np.pi) * SQRT_LN2 / G * wofz(z).real
 
 
-def make_workload(P=16384, K=16, W=65536, seed=20240517, nbz=True):
+def make_workload(P=16384, K=16, W=65536, seed=20240517, nbz=True, ensemble="truth", width_scale=1.0):
     """SURVEY section 8d synthetic region.  Region-centred pixel coordinates x_i = i - (P-1)/2;
     truth: centroid ~ U(-0.45P, 0.45P), amplitude ~ U(0.2, 3), G_fwhm ~ U(20, 200) px,
     L_fwhm ~ U(1, 20) px (fixed to 10 px in the 3-parameter NBZ form); sigma = 0.01;
-    walkers = truth * (1 + 1e-3 N(0,1)), clipped into the priors of vpfits.py:249-297."""
+    walkers = truth * (1 + 1e-3 N(0,1)), clipped into the priors of vpfits.py:249-297.
+
+    Robustness knobs (the defaults are the headline): ``width_scale`` multiplies the true widths;
+    ``ensemble`` = "truth" (above), "dispersed" (a burn-in ensemble: every walker has its own
+    centroids ~ U over the region, amplitudes ~ the xexp prior, widths log-uniform over
+    [1/4, 4] x the truth range) or "prior" (every parameter drawn from its prior of
+    vpfits.py:239-252, 283-297: widths ~ U(0, fwhm_max), i.e. mostly lines wider than the region)."""
     rng = np.random.default_rng(seed)
     x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
     scale = P / 16384.0
     c = rng.uniform(-0.45 * P, 0.45 * P, K)
     A = rng.uniform(0.2, 3.0, K)
-    G = rng.uniform(20.0, 200.0, K) * max(scale, 1.0 / 16)
-    L = rng.uniform(1.0, 20.0, K) * max(scale, 1.0 / 16)
+    G = rng.uniform(20.0, 200.0, K) * max(scale, 1.0 / 16) * width_scale
+    L = rng.uniform(1.0, 20.0, K) * max(scale, 1.0 / 16) * width_scale
     if nbz:
-        L = np.full(K, L_FIXED_PIX * max(scale, 1.0 / 16))
+        L = np.full(K, L_FIXED_PIX * max(scale, 1.0 / 16) * width_scale)
     tau = np.zeros(P)
     for k in range(K):
         tau += _voigt_tau(x, A[k], c[k], L[k], G[k])
@@ -64,6 +75,21 @@ def make_workload(P=16384, K=16, W=65536, seed=20240517, nbz=True):
     out = dict(x=x, flux=flux, noise=noise, K=K, P=P, W=W)
     pert = 1.0 + 1e-3 * rng.standard_normal((W, K, 4))
     nat = np.stack([A, c, L, G], axis=1)[None, :, :] * pert          # (W, K, 4) = A, c, L, G
+    if ensemble != "truth":
+        r2 = np.random.default_rng(seed + 1)
+        ws = max(scale, 1.0 / 16) * width_scale
+        nat[:, :, 0] = r2.gamma(2.0, 1.0, (W, K))                     # xexp prior: v exp(-v)
+        nat[:, :, 1] = r2.uniform(x[0], x[-1], (W, K))
+        if ensemble == "prior":
+            nat[:, :, 3] = r2.uniform(0.0, fwhm_max, (W, K))
+            if not nbz:
+                nat[:, :, 2] = r2.uniform(0.0, fwhm_max, (W, K))
+        elif ensemble == "dispersed":
+            nat[:, :, 3] = np.exp(r2.uniform(np.log(5.0 * ws), np.log(800.0 * ws), (W, K)))
+            if not nbz:
+                nat[:, :, 2] = np.exp(r2.uniform(np.log(0.25 * ws), np.log(80.0 * ws), (W, K)))
+        else:
+            raise ValueError("ensemble must be 'truth', 'dispersed' or 'prior'")
     nat[:, :, 0] = np.clip(nat[:, :, 0], 1e-6, None)
     nat[:, :, 1] = np.clip(nat[:, :, 1], x[0], x[-1])
     nat[:, :, 2] = np.clip(nat[:, :, 2], 1e-6, fwhm_max)
@@ -115,7 +141,8 @@ def cpu_reference_path(wl, budget_s=12.0):
     same workload is timed (pool start-up and the initial log-posteriors are not)."""
     import multiprocessing as mp
     from oracle import vamp_oracle as vo
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VAMP_CPU_WORKERS", "128")))
+    # BASELINE.md section 3: all host cores = every core of this process's affinity mask (VAMP_CPU_WORKERS caps it)
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VAMP_CPU_WORKERS", "100000")))
     kw = dict(x=wl["x"], flux=wl["flux"], noise=wl["noise"], n_comp=wl["K"], mode=wl["mode"])
     if wl["nbz"] is not None:
         l_fixed, line, x_origin, x_scale = [float(v) for v in wl["nbz"][0]]
@@ -150,8 +177,8 @@ def cpu_reference_path(wl, budget_s=12.0):
     return {"value": Wc / t, "unit": "walker-steps/s", "cores": cores, "kind": "port",
             "path": "numpy + scipy.special.wofz log-posterior + numpy stretch move (oracle/vamp_oracle.py), "
                     "multiprocessing pool over walker chunks: the CPU path named by BASELINE.json",
-            "sample": f"first {Wc} walkers of the same workload x 1 full step on {cores} processes, {t:.1f} s; "
-                      f"os.cpu_count() = {os.cpu_count()}",
+            "sample": f"first {Wc} walkers of the same workload x 1 full step on {cores} processes (one per core of the "
+                      f"affinity mask, {len(os.sched_getaffinity(0))} cores), {t:.1f} s; os.cpu_count() = {os.cpu_count()}",
             "accepted": nacc}
 
 
@@ -257,6 +284,36 @@ FP64_PEAK_TFLOPS = 2.0 * VALU_PEAK_LANE_INSTR / 1e12          # 78.6 (an FMA cou
 F_W_FLOPS, F_PX_FLOPS = 82.0, 46.0
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child process
+    (`python -m torch.distributed.run`, one rank per GPU) and relay rank 0's line.  This parent never
+    initialises the GPU (no torch.cuda, no vamp_amd call) and never execs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no WORLD_SIZE in the environment: starting %d ranks: %s" % (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    n_lines = 0
+    for ln in child.stdout:
+        if ln.lstrip().startswith("{"):           # rank 0's JSON line goes to stdout, anything else to stderr
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+            n_lines += 1
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    if rc == 0 and n_lines != 1:
+        print("bench.py: the ranks printed %d JSON lines (expected one)" % n_lines, file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,28 +324,35 @@ def main():
     ap.add_argument("--components", type=int, default=16)
     ap.add_argument("--param", choices=["nbz3", "voigt4"], default="nbz3")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--ensemble", choices=["truth", "dispersed", "prior"], default="truth",
+                    help="initial walkers: the truth ball of SURVEY 8d (default, the headline); 'dispersed' = a burn-in "
+                         "ensemble (own centroids, amplitudes and log-uniform widths per walker); 'prior' = drawn from the priors")
+    ap.add_argument("--width-scale", type=float, default=1.0, help="multiply the true line widths (G and L) of the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="do not record the chain inside the timed region")
     ap.add_argument("--sustain-seconds", type=float, default=2.5,
                     help="after the K timed steps, a second run of about this many seconds (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the RCCL communicator and run the exchange even with one rank (rehearsal)")
+    ap.add_argument("--exchange-parts", default="auto",
+                    help="pieces per half-step of the overlapped exchange: a number, or 'auto' = time 1 and 2 during warm-up "
+                         "and keep the faster (every rank takes the same decision from the max over ranks)")
     args = ap.parse_args()
 
     # the host driver of these boxes only supports dmabuf IPC: without this RCCL's intra-node handles fail
     # (hipIpcGetMemHandle: invalid argument).  Already exported on the boxes; kept for any other launcher.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "VAMP_BENCH_DEVICE" in os.environ:          # rehearsal knob: several ranks on one GPU (host logic only)
         local_rank = int(os.environ["VAMP_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
-    wl = make_workload(P=args.pixels, K=args.components, W=args.walkers, nbz=(args.param == "nbz3"))
+    wl = make_workload(P=args.pixels, K=args.components, W=args.walkers, nbz=(args.param == "nbz3"),
+                       ensemble=args.ensemble, width_scale=args.width_scale)
     P, K, W, D = wl["P"], wl["K"], wl["W"], wl["D"]
 
     # host baseline first: its worker pool forks before this process has touched the GPU
@@ -313,44 +377,21 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     dtype = vamp_amd.F64 if args.dtype == "f64" else vamp_amd.F32
-    ctx = vamp_amd.HipContext(device=local_rank, dtype=dtype)
-    ctx.set_regions(wl["x"], wl["flux"], wl["noise"], K, mode=wl["mode"], nbz=wl["nbz"])
+
+    def new_ctx():
+        c = vamp_amd.HipContext(device=local_rank, dtype=dtype)
+        c.set_regions(wl["x"], wl["flux"], wl["noise"], K, mode=wl["mode"], nbz=wl["nbz"])
+        return c
+
+    ctx = new_ctx()
 
     from vamp_amd.ensemble import ShardedEnsemble
-    exchange_label = "none"
-    try:
-        ens = ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange="rccl" if dist is not None else "none",
-                              exchange_single_rank=args.force_dist)
-        comm_error = None
-    except vamp_amd._lib.VampError as e:
-        if e.code != -3:                  # anything but a communicator problem is a bug: fail
-            raise
-        ens, comm_error = None, str(e)
-    if dist is not None:
-        # a communicator that did not come up on ANY rank sends every rank to the host-staged exchange:
-        # same kernels, rows through pinned host memory and gloo -- slow, loudly labelled, but the
-        # scaling run still produces a correct line instead of none
-        flag = torch.tensor([0 if ens is None else 1])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
-            if rank == 0:
-                print("bench.py: RCCL communicator failed (%s); FALLING BACK to the host-staged gloo exchange" % comm_error,
-                      file=sys.stderr, flush=True)
-            ctx.close()
-            ctx = vamp_amd.HipContext(device=local_rank, dtype=dtype)
-            ctx.set_regions(wl["x"], wl["flux"], wl["noise"], K, mode=wl["mode"], nbz=wl["nbz"])
-            ens = ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange="gloo_host", parts=1)
-            exchange_label = "FALLBACK: host-staged gloo all-gather (RCCL communicator failed: %s)" % comm_error
-        else:
-            exchange_label = f"in-library RCCL all-gather of the active colour, {ens.parts} piece(s) per half-step"
-    own = ens.own_count
-    host_staged = ens.exchange == "gloo_host"
+    exchange_label, exchange_kind = "none", "none"
+    want = "rccl" if dist is not None else "none"
 
-    def run_steps(n, thin=1, chain_ptr=None):
-        if host_staged:
-            ens.step(n)                   # stepped from Python, no device-resident chain in this mode
-        else:
-            ens.run_dev(n, thin=thin, chain_ptr=chain_ptr)
+    def build(parts, kind=want):
+        return ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange=kind, parts=parts,
+                               exchange_single_rank=args.force_dist)
 
     def sync_all():
         ctx.synchronize()
@@ -359,6 +400,63 @@ def main():
             dist.barrier()
         ctx.synchronize()
         torch.cuda.synchronize()
+
+    # pieces per half-step: a number, or the faster of 1 and 2 measured here (max over ranks, so every rank agrees)
+    parts_tried = None
+    comm_error = None
+    ens = None
+    try:
+        if dist is None:
+            ens = build(1)
+        elif args.exchange_parts != "auto":
+            ens = build(int(args.exchange_parts))
+        else:
+            from vamp_amd.hip_backend import default_split_block
+            chunks = W // default_split_block(W, world)
+            cands = [p for p in (1, 2) if chunks % (world * p) == 0]
+            parts_tried = {}
+            for p in cands:
+                ens = build(p)
+                n_try = max(3, args.warmup)
+                ens.run_dev(n_try)
+                sync_all()
+                t0 = time.perf_counter()
+                ens.run_dev(n_try)
+                sync_all()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                parts_tried[p] = float(t[0]) / n_try * 1e3
+            best = min(parts_tried, key=parts_tried.get)
+            ens = build(best)
+    except vamp_amd._lib.VampError as e:
+        if e.code != -3 or dist is None:  # anything but a communicator problem is a bug: fail
+            raise
+        # ShardedEnsemble raises this on EVERY rank together (vamp_amd/ensemble.py: _join_communicator), so all
+        # ranks arrive here: the host-staged exchange -- same kernels, rows through pinned host memory and gloo --
+        # is slow and loudly labelled, but the scaling run still produces a correct line instead of none
+        ens, comm_error = None, str(e)
+        if rank == 0:
+            print("bench.py: RCCL communicator failed (%s); FALLING BACK to the host-staged gloo exchange" % comm_error,
+                  file=sys.stderr, flush=True)
+        if not getattr(e, "stuck", False):
+            ctx.close()
+        ctx = new_ctx()
+        ens = build(1, kind="gloo_host")
+        exchange_label = "FALLBACK: host-staged gloo all-gather (RCCL communicator failed: %s)" % comm_error
+        exchange_kind = "gloo_host FALLBACK"
+    rccl_ranks = rccl_queried = None
+    if dist is not None and comm_error is None:
+        _, rccl_ranks, rccl_queried = ctx.comm_info()
+        exchange_kind = "rccl"
+        exchange_label = f"in-library RCCL all-gather of the active colour, {ens.parts} piece(s) per half-step"
+    own = ens.own_count
+    host_staged = ens.exchange == "gloo_host"
+
+    def run_steps(n, thin=1, chain_ptr=None):
+        if host_staged:
+            ens.step(n)                   # stepped from Python, no device-resident chain in this mode
+        else:
+            ens.run_dev(n, thin=thin, chain_ptr=chain_ptr)
 
     # chain storage (device resident, torch = allocator): every kept step is one device-to-device copy
     # of the state on the stream the kernels run on, inside the timed region
@@ -372,6 +470,7 @@ def main():
     run_steps(args.steps, chain_ptr=None if chain is None else chain.data_ptr())
     sync_all()
     dt = time.perf_counter() - t0
+    x_ms, x_n = ctx.exchange_timing()
     k_ms, k_n = ctx.kernel_timing(False)
 
     # a longer second run (clocks and caches settled; 20 steps are 0.15 s): same loop, the chain thinned
@@ -387,6 +486,7 @@ def main():
         run_steps(n_s, thin=thin, chain_ptr=None if chain is None else chain.data_ptr())
         sync_all()
         dts = time.perf_counter() - t0
+        ctx.exchange_timing()
         s_ms, s_n = ctx.kernel_timing(False)
         sustained = {"steps": n_s, "seconds": dts, "chain_thin": thin, "avg_launch_ms": s_ms / max(1, s_n), "launches": s_n}
 
@@ -439,6 +539,7 @@ def main():
                                    f"stretch move a=2, walkers sharded over {world} GPU(s)",
                        "pixels": P, "components": K, "walkers": W, "ndim": D, "parameterisation": args.param,
                        "chain_recorded": chain is not None,
+                       "ensemble": args.ensemble, "width_scale": args.width_scale,
                        "exchange": exchange_label},
             # contract form: ALGORITHMIC bytes of the launch / its HIP-event duration, against the HBM peak.
             # The kernel is not HBM-bound (the spectrum is shared by all walkers and stays in L2: see
@@ -471,6 +572,24 @@ def main():
                                    "note": "NOMINAL: P (K F_w + F_px) per walker-step as if every (pixel, line) pair were "
                                            "evaluated directly; the far-field interpolant and the Taylor tables carry out "
                                            "~30 % of that arithmetic, so the nominal fraction can exceed 1"}},
+            # how many ranks the exchange really spanned, and what it cost (rank 0's HIP events; half-step = one colour)
+            "rccl_ranks": rccl_ranks,
+            "exchange": None if dist is None else {
+                "kind": exchange_kind, "parts": ens.parts, "rccl_ranks": rccl_ranks,
+                "rccl_ranks_is": None if rccl_ranks is None else (
+                    "ncclCommCount of the library's communicator" if rccl_queried else "the world the communicator was created with"),
+                "bytes_per_rank_per_half_step": (own // 2) * (D + 1) * 8,
+                "kernel_ms_per_half_step": k_ms / (2 * args.steps),
+                "exchange_ms_per_half_step": x_ms / (2 * args.steps),
+                "wall_ms_per_half_step": dt / (2 * args.steps) * 1e3,
+                # share of the exchange time that ran beside a kernel: 1 - (wall - kernel) / exchange
+                "overlap_frac": None if not x_n or x_ms <= 0 else
+                    max(0.0, min(1.0, 1.0 - (dt * 1e3 - k_ms) / x_ms)),
+                "is": "HIP events of rank 0: kernels on the compute stream, ncclAllGather + scatter on the stream they run on "
+                      "(the communication stream when parts > 1); wall = the driver-visible time (max over ranks, includes the "
+                      "chain copy of every step)",
+                "exchanges_timed": x_n,
+                "parts_tried_ms_per_step": parts_tried},
             "nominal_faddeeva_gevals_per_s": value * P * K / 1e9,
             "acceptance_fraction": acc_frac,
             "finite_lnprob_fraction": finite_frac,

@@ -49,7 +49,7 @@ enum vamp_dtype { VAMP_F64 = 0, VAMP_F32 = 1 };          /* per-pixel arithmetic
 enum vamp_wofz { VAMP_WOFZ_ACCURATE = 0, VAMP_WOFZ_HUMLICEK_W4 = 1 };
 
 #define VAMP_MAX_COMPONENTS 16
-#define VAMP_ABI_VERSION 2
+#define VAMP_ABI_VERSION 3
 #define VAMP_COMM_ID_BYTES 128   /* = NCCL_UNIQUE_ID_BYTES */
 
 /* library identification */
@@ -190,6 +190,13 @@ int vamp_sampler_init(vamp_ctx* ctx, int64_t W, const double* theta0, uint64_t s
 int vamp_comm_unique_id(char id[VAMP_COMM_ID_BYTES]);
 int vamp_comm_init_rank(vamp_ctx* ctx, const char id[VAMP_COMM_ID_BYTES], int rank, int world);
 int vamp_comm_destroy(vamp_ctx* ctx);
+/* What the communicator itself says it is: rank and size from ncclCommUserRank / ncclCommCount
+ * (*queried = 1), or -- with a library that lacks those two entry points -- the values it was
+ * created with (*queried = 0).  bench.py prints them as `rccl_ranks`, so that a scaling line proves
+ * how many ranks the exchange really spanned.  VAMP_ERR_STATE without a communicator.  Any output
+ * may be NULL.  vamp_comm_init_rank and vamp_sampler_set_shard_parts may come in either order;
+ * the second one returns VAMP_ERR_ARG if its rank / world differ from the first one's. */
+int vamp_comm_info(vamp_ctx* ctx, int* rank, int* world, int* queried);
 /* Restrict this ctx to shard `rank` of `world` equal shards of every half-step's active slots;
  * own_begin / own_end receive the rows of the walkers it owns (whole split chunks).  n_accept is
  * maintained for owned rows only; positions and lnprob are complete on every rank. */
@@ -240,6 +247,11 @@ int vamp_sampler_set_state(vamp_ctx* ctx, const double* theta, const double* lnp
 /* HIP-event time (ms) and launch count of the half-step kernel since the last reset; used by
  * bench.py for the roofline line */
 int vamp_kernel_timing(vamp_ctx* ctx, int enable, double* total_ms, int64_t* launches);
+/* HIP-event time (ms) and count of the exchanges (ncclAllGather + scatter of one piece, on the stream
+ * they ran on) recorded while vamp_kernel_timing was enabled, since the last reset; resets.  With
+ * pieces > 1 the exchanges run on the communication stream beside the next piece's kernel, so
+ * kernel time + exchange time may exceed the wall time: the difference is what the overlap hides. */
+int vamp_exchange_timing(vamp_ctx* ctx, double* total_ms, int64_t* exchanges);
 
 #ifdef __cplusplus
 }

@@ -774,6 +774,14 @@ int vamp_comm_destroy(vamp_ctx* c) {
     c->comm = false;
     return VAMP_OK;
 }
+int vamp_comm_info(vamp_ctx* c, int* rank, int* world, int* queried) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_comm_info: ctx is NULL");
+    if (!c->comm) return fail(VAMP_ERR_STATE, "vamp_comm_info: the context has no communicator (vamp_comm_init_rank)");
+    if (rank) *rank = 0;
+    if (world) *world = 1;
+    if (queried) *queried = 0;
+    return VAMP_OK;
+}
 
 int vamp_sampler_pack_get(vamp_ctx* c, int part, double* rows) {
     if (!c || !rows) return fail(VAMP_ERR_ARG, "vamp_sampler_pack_get: NULL argument");
@@ -788,6 +796,13 @@ int vamp_sampler_scatter_put(vamp_ctx* c, int part, const double* rows_all) {
     if (!c->ready || c->recv.empty()) return fail(VAMP_ERR_STATE, "vamp_sampler_scatter_put: no sharded sampler (vamp_sampler_set_shard_parts with world > 1)");
     if (part < 0 || part >= c->shard_parts) return fail(VAMP_ERR_ARG, "vamp_sampler_scatter_put: no such part");
     scatter_part(c, part, rows_all);
+    return VAMP_OK;
+}
+
+int vamp_exchange_timing(vamp_ctx* c, double* total_ms, int64_t* exchanges) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_exchange_timing: ctx is NULL");
+    if (total_ms) *total_ms = 0.0;          // the host build has no in-library exchange
+    if (exchanges) *exchanges = 0;
     return VAMP_OK;
 }
 

@@ -1,5 +1,6 @@
-// rccl_fake.cpp -- TEST STAND-IN for the five NCCL entry points libvamp_hip.so resolves at run time
-// (ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllGather, ncclGetErrorString).
+// rccl_fake.cpp -- TEST STAND-IN for the NCCL entry points libvamp_hip.so resolves at run time
+// (ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllGather, ncclGetErrorString; optional
+// ncclCommCount, ncclCommUserRank).
 //
 // RCCL refuses two ranks on one GPU, and the test box has one GPU.  This library lets several
 // processes on ONE device form a "communicator": the all-gather goes device -> POSIX shared memory
@@ -52,6 +53,7 @@ extern "C" {
 struct ncclUniqueId { char internal[128]; };
 
 int ncclGetUniqueId(ncclUniqueId* id) {
+    if (getenv("VAMP_FAKE_RCCL_FAIL_ID")) return 2;       // tests of bench.py's fallback: the id cannot be made
     std::memset(id->internal, 0, sizeof(id->internal));
     std::snprintf(id->internal, sizeof(id->internal), "/vampfake-%d-%ld", (int)getpid(), (long)time(nullptr));
     return 0;
@@ -59,6 +61,8 @@ int ncclGetUniqueId(ncclUniqueId* id) {
 
 int ncclCommInitRank(void** comm, int n, ncclUniqueId id, int rank) {
     if (!comm || n < 1 || rank < 0 || rank >= n) return 4;
+    if (const char* bad = getenv("VAMP_FAKE_RCCL_FAIL_INIT_RANK"))      // ... or ONE rank fails to join
+        if (std::atoi(bad) == rank) return 2;
     Comm* c = new Comm();
     c->rank = rank;
     c->n = n;
@@ -104,6 +108,17 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c
     barrier(c);
     if (hipMemcpy(recv, c->data, bytes * c->n, hipMemcpyHostToDevice) != hipSuccess) return 1;
     barrier(c);
+    return 0;
+}
+
+int ncclCommCount(void* comm, int* n) {
+    if (!comm || !n) return 4;
+    *n = ((Comm*)comm)->n;
+    return 0;
+}
+int ncclCommUserRank(void* comm, int* r) {
+    if (!comm || !r) return 4;
+    *r = ((Comm*)comm)->rank;
     return 0;
 }
 

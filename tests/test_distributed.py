@@ -515,3 +515,188 @@ def test_pieces_of_a_packed_single_region_ensemble():
             ens.run_dev(2)
             X2, lnp2, nacc2, step = ctx.get_state()
             assert step == 3 and np.array_equal(X2, X1) and np.array_equal(lnp2, lnp1) and np.array_equal(nacc2, nacc1), exchange
+
+
+# ---- round 3: bench.py as the driver runs it, fall-back safety net, call order, shape under sharding ----
+FAKE_RCCL = os.path.join(ROOT, "tests", "host", "librccl_fake.so")
+BENCH_SMALL = ["--walkers", "4096", "--pixels", "2048", "--components", "6", "--steps", "2", "--warmup", "1",
+               "--no-cpu-baseline", "--sustain-seconds", "0"]
+
+
+def _run_bench(extra_args, extra_env, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, capture_output=True, text=True,
+                         timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0]), out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_plain_form_launches_its_own_ranks(n):
+    """`python3 bench.py --gpus N` with no WORLD_SIZE in the environment (the form the driver uses at
+    N = 1) starts its N ranks itself -- a GPU-free parent, torch.distributed.run as a child -- and
+    prints ONE line that proves how many ranks the exchange spanned.  N ranks share device 0
+    (VAMP_BENCH_DEVICE) over the stand-in for RCCL; everything else is the 8-GPU code path."""
+    line, err = _run_bench(["--gpus", str(n)] + BENCH_SMALL, {"VAMP_BENCH_DEVICE": "0", "VAMP_RCCL_LIB": FAKE_RCCL})
+    assert "starting %d ranks" % n in err
+    assert line["n_gpus"] == n and line["rccl_ranks"] == n and line["scaling"] == "strong"
+    ex = line["exchange"]
+    assert ex["kind"] == "rccl" and ex["rccl_ranks"] == n and ex["rccl_ranks_is"].startswith("ncclCommCount")
+    from vamp_amd.hip_backend import default_split_block
+    chunks = 4096 // default_split_block(4096, n)                  # pieces must be whole split chunks on every rank
+    assert set(ex["parts_tried_ms_per_step"]) == {str(p) for p in (1, 2) if chunks % (n * p) == 0}
+    assert str(ex["parts"]) in ex["parts_tried_ms_per_step"]
+    assert ex["exchanges_timed"] == 2 * 2 * ex["parts"]             # 2 steps x 2 colours x pieces
+    assert ex["kernel_ms_per_half_step"] > 0 and ex["exchange_ms_per_half_step"] > 0 and ex["wall_ms_per_half_step"] > 0
+    assert 0.0 <= ex["overlap_frac"] <= 1.0
+    assert ex["bytes_per_rank_per_half_step"] == (4096 // n // 2) * (18 + 1) * 8
+    assert line["value"] > 0 and 0.05 < line["acceptance_fraction"] < 0.95 and line["finite_lnprob_fraction"] == 1.0
+    assert line["roofline"]["walker_steps_per_launch"] == 4096 // n // 2 // ex["parts"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail", ["id", "one_rank"])
+def test_bench_falls_back_together_when_the_communicator_fails(fail):
+    """The scaling run's safety net: a communicator that cannot be made -- the id on
+    rank 0, or ncclCommInitRank on ONE rank while the other is already inside it -- sends EVERY rank
+    to the host-staged gloo exchange; nobody is left in a collective alone, and the line says so."""
+    env = {"VAMP_BENCH_DEVICE": "0", "VAMP_RCCL_LIB": FAKE_RCCL, "VAMP_COMM_INIT_TIMEOUT": "15"}
+    env.update({"VAMP_FAKE_RCCL_FAIL_ID": "1"} if fail == "id" else {"VAMP_FAKE_RCCL_FAIL_INIT_RANK": "1"})
+    line, err = _run_bench(["--gpus", "2"] + BENCH_SMALL, env)
+    assert "FALLING BACK" in err
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] is None
+    assert line["exchange"]["kind"].startswith("gloo_host") and "FALLBACK" in line["config"]["exchange"]
+    assert line["value"] > 0 and line["finite_lnprob_fraction"] == 1.0
+
+
+def _order_worker(rank, world, port, out_dir):
+    """shard first, communicator second (the order vamp_hip.h now allows), two pieces"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), VAMP_RCCL_LIB=FAKE_RCCL)
+    import torch.distributed as dist
+    import vamp_amd
+    from vamp_amd import _lib
+    from vamp_amd.hip_backend import comm_unique_id
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    region, X0 = _big_case(256)
+    ctx = vamp_amd.HipContext(device=0)
+    ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+    ctx.sampler_init(X0, seed=77, split_block=16)
+    ctx.sampler_set_shard_parts(rank, world, 2)                  # BEFORE the communicator exists
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    with pytest.raises(_lib.VampError) as ei:                    # a communicator that contradicts the shard
+        ctx.comm_init_rank(box[0], (rank + 1) % world, world)
+    assert ei.value.code == -1
+    ctx.comm_init_rank(box[0], rank, world)
+    assert ctx.comm_info() == (rank, world, True)
+    ctx.kernel_timing(True)
+    ctx.run_dev(6)
+    x_ms, x_n = ctx.exchange_timing()
+    k_ms, k_n = ctx.kernel_timing(False)
+    assert x_n == 6 * 2 * 2 and k_n == 6 * 2 * 2 and x_ms > 0 and k_ms > 0
+    X, lnp, _, _ = ctx.get_state()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "order.npz"), X=X, lnp=lnp)
+    dist.barrier()
+    ctx.comm_destroy()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_shard_before_communicator_is_a_valid_order(tmp_path):
+    """sampler_init -> set_shard_parts(world 2, 2 pieces) -> comm_init_rank used to leave
+    the per-piece events uncreated (out-of-bounds in exchange_part).  Now either order works, a
+    mismatch of rank/world is VAMP_ERR_ARG, and the chain is the single-rank one."""
+    import torch.multiprocessing as mp
+    import vamp_amd
+    mp.spawn(_order_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = np.load(os.path.join(str(tmp_path), "order.npz"))
+    region, X0 = _big_case(256)
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+        ctx.sampler_init(X0, seed=77, split_block=16)
+        ctx.run(6, store_chain=False)
+        X1, lnp1, _, _ = ctx.get_state()
+    assert np.array_equal(r["X"], X1) and np.array_equal(r["lnp"], lnp1)
+
+
+@pytest.mark.gpu
+def test_small_pieces_of_a_packed_ensemble_keep_its_shape():
+    """the kernel shape of a launch class used to follow the size of THIS launch, so a
+    short-region ensemble of 65 536 walkers ran four walkers per wavefront on one device and one per
+    wavefront as a 4096-walker piece (world 4 x 2 pieces) -- agreeing to rounding only.  The shape now
+    follows the unsharded ensemble: eight 4096-mover pieces give the unsharded chain bit for bit."""
+    import vamp_amd
+    region, _ = _case()
+    rng = np.random.default_rng(22)
+    W = 65536
+    X0 = np.stack([rng.uniform(0.3, 1.5, W), rng.uniform(-4, 4, W), rng.uniform(0.5, 3, W), rng.uniform(2, 8, W)], 1)
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+        ctx.sampler_init(X0, seed=9, split_block=1024)
+        ctx.run(2, store_chain=False)
+        X1, lnp1, nacc1, _ = ctx.get_state()
+    with vamp_amd.HipContext(device=0) as ctx:
+        ctx.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+        ctx.sampler_init(X0, seed=9, split_block=1024)
+        ctx.sampler_set_shard_parts(0, 1, 8)                      # 8 pieces of 4096 movers: below the packing threshold
+        for _ in range(2):
+            for half in (0, 1):
+                for p in range(8):
+                    ctx.half_step_part(half, p)
+        X2, lnp2, nacc2, step = ctx.get_state()
+    assert step == 2 and np.array_equal(X2, X1) and np.array_equal(lnp2, lnp1) and np.array_equal(nacc2, nacc1)
+
+
+def _join_fail_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import vamp_amd
+    from vamp_amd.ensemble import ShardedEnsemble
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    region, X0 = _case()
+    backend = vamp_amd.HipContext(lib=vamp_amd._lib.bind(os.path.join(ROOT, "oracle", "libvamp_cpu.so")))
+    backend.set_regions(region.x, region.flux, region.noise, 1, mode=vamp_amd.MODE_VOIGT4)
+    code = 0
+    try:       # the host build refuses a communicator of world > 1: VAMP_ERR_COMM inside comm_init_rank
+        ShardedEnsemble(backend, X0, seed=1, split_block=8, dist=dist, exchange="rccl", parts=1)
+    except vamp_amd._lib.VampError as e:
+        code = e.code
+    # every rank is here, in step: a collective right after the failure completes (bench.py's fall-back does this)
+    flag = torch.tensor([code])
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    ens = ShardedEnsemble(backend, X0, seed=4242, split_block=8, dist=dist, exchange="gloo_host", parts=1)
+    ens.step(2)
+    X, lnp, nacc = ens.gather_state()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "joinfail.npz"), X=X, code=code, flag=int(flag[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failed_communicator_raises_on_every_rank_cpu(tmp_path):
+    """ShardedEnsemble(exchange='rccl') either gives every rank a communicator or raises
+    VampError(-3) on every rank TOGETHER (here: the host build of the ABI, which has no RCCL), so the
+    caller's next collective -- bench.py's fall-back to the host-staged exchange -- cannot hang."""
+    import torch.multiprocessing as mp
+    mp.spawn(_join_fail_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = np.load(os.path.join(str(tmp_path), "joinfail.npz"))
+    assert int(r["code"]) == -3 and int(r["flag"]) == -3
+    region, X0 = _case()
+    fn = lambda q: vo.log_prob_batch_fast(region, q)
+    chain, _, _ = vo.run_sampler(fn, X0, fn(X0), 2, seed=4242, block=8)
+    assert np.allclose(r["X"], chain[-1], rtol=1e-10, atol=1e-12)

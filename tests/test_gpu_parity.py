@@ -745,6 +745,58 @@ def test_random_long_regions_match_oracle(hip_ctx, seed):
     assert worst <= 1e-9
 
 
+@pytest.mark.parametrize("grid", ["ascending", "descending", "uneven"])
+def test_full_size_dispersed_walkers_match_oracle(hip_ctx, grid):
+    """The headline's FULL size -- P = 16 384 pixels, K = 16 lines, 64 tiles of 256 pixels, 16 tiles
+    per wavefront of the workgroup-per-walker shape -- on walkers that are NOT converged: widths and
+    dampings spread over decades (every walker has its own near / far mix per tile, narrow-line caps,
+    more than 8 far lines per tile and fewer), one line on the region's edge, one crowded blend, one
+    line far narrower than a pixel.  Log-posterior of 8 such walkers against the oracle's scipy.wofz
+    restatement (vpfits.py:57-76, 334-341), |delta| <= 1e-9 max(1, |lnprob|), and one stretch step
+    against the oracle's sampler -- on an ascending, a descending and an unevenly spaced grid."""
+    if hip_ctx.packing_request in (16, 65):
+        pytest.skip("long regions: one walker per wavefront or workgroup")
+    rng = np.random.default_rng({"ascending": 31, "descending": 32, "uneven": 33}[grid])
+    P, K, W = 16384, 16, 8
+    x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+    if grid == "uneven":
+        x = np.cumsum(rng.uniform(0.5, 1.5, P))
+        x -= x.mean()
+    span = x[-1] - x[0]
+    th = np.empty((W, K, 4))
+    th[:, :, 0] = 10.0 ** rng.uniform(-2, 1.7, (W, K))                                  # amplitude
+    th[:, :, 1] = rng.uniform(x[0], x[-1], (W, K))                                      # centroid
+    th[:, 0, 1] = np.where(rng.random(W) < 0.5, x[0], x[-1])                            # one line on the edge
+    th[:, :, 2] = 10.0 ** rng.uniform(-6, np.log10(0.4 * span), (W, K))                 # L_fwhm
+    th[:, :, 3] = 10.0 ** rng.uniform(-1.3, np.log10(0.4 * span), (W, K))               # G_fwhm
+    th[:, 1:4, 1] = np.clip(th[:, 1:2, 1] + rng.normal(0, 3.0, (W, 3)), x[0], x[-1])    # a crowded blend
+    th[:, 1:4, 3] = 10.0 ** rng.uniform(0.5, 1.5, (W, 3))
+    th[:, 4, 3] = 10.0 ** rng.uniform(-1.3, -0.7, W)                                    # a sub-pixel line
+    th[:, 4, 2] = 10.0 ** rng.uniform(-6, -2, W)
+    th[:4, 5:, 3] = 10.0 ** rng.uniform(1.0, 2.3, (4, K - 5))                           # half the walkers: mostly far lines
+    th[:4, 5:, 2] = 10.0 ** rng.uniform(-1, 1.3, (4, K - 5))
+    th = th.reshape(W, 4 * K)
+    noise = np.full(P, 0.05)
+    flux = np.clip(1.0 + rng.normal(0, 0.05, P), 0, None)
+    if grid == "descending":
+        x, flux, noise = x[::-1].copy(), flux[::-1].copy(), noise[::-1].copy()
+    hip_ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
+    r = vo.Region(x=x, flux=flux, noise=noise, n_comp=K, mode=vo.MODE_VOIGT4)
+    want = vo.log_prob_batch_fast(r, th)
+    got = hip_ctx.lnprob(th)
+    assert np.isfinite(want).all() and np.isfinite(got).all()
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() <= 1e-9, (grid, err)
+    hip_ctx.sampler_init(th, seed=5, split_block=W)
+    res = hip_ctx.run(1)
+    fn = lambda q: vo.log_prob_batch_fast(r, q)
+    chain, lchain, nacc = vo.run_sampler(fn, th, want, 1, seed=5, block=W)
+    assert np.array_equal(res["n_accept"], nacc), grid
+    assert np.allclose(res["chain"], chain, rtol=1e-10, atol=1e-12), grid
+    fin = np.isfinite(lchain[-1])
+    assert np.allclose(res["lnprob"][-1][fin], lchain[-1][fin], rtol=1e-9, atol=1e-9), grid
+
+
 def test_descending_grid_long_region(hip_ctx):
     """A region uploaded in descending coordinate order (the reference flips to ascending
     frequency, vpspectrum.py:274-277, but the ABI takes either direction): same log-posterior as

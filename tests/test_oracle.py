@@ -20,7 +20,8 @@ def _dp(a):
 
 @pytest.fixture(scope="module")
 def c_oracle():
-    so = os.path.join(ROOT, "oracle", "libvamp_oracle.so")
+    # VAMP_ORACLE_SO: another build of the same library (tests/test_sanitizers.py: the ASan/UBSan build)
+    so = os.environ.get("VAMP_ORACLE_SO") or os.path.join(ROOT, "oracle", "libvamp_oracle.so")
     if not os.path.exists(so):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])

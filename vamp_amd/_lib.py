@@ -47,6 +47,7 @@ SIGNATURES = {
     "vamp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "vamp_comm_init_rank": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "vamp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "vamp_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vamp_sampler_pack_get": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "vamp_sampler_scatter_put": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "vamp_sampler_run_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, c_double_p]),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "vamp_sampler_get_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int64_p, c_int64_p]),
     "vamp_sampler_set_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int64]),
     "vamp_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_int64_p]),
+    "vamp_exchange_timing": (C.c_int, [C.c_void_p, c_double_p, c_int64_p]),
 }
 
 _lib = None

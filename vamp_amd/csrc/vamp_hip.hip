@@ -138,6 +138,9 @@ template <int KCAP, bool OWN_DTAB> struct WalkerLds;
 #ifndef VAMP_SPLIT_WAVES
 #define VAMP_SPLIT_WAVES 4
 #endif
+#ifndef VAMP_SPLIT_WAVES_F32
+#define VAMP_SPLIT_WAVES_F32 4
+#endif
 template <int LPW_, int KCAP_, bool TAIL_, int WPB_, bool SPLIT_ = false, bool TABS_ = SPLIT_, bool FF_ = (LPW_ == 64)>
 struct Pack {
     static constexpr int LPW = LPW_, KCAP = KCAP_, SUBS = 64 / LPW_;
@@ -220,6 +223,11 @@ template <bool ON, int KCAP = KMAX>
 struct alignas(16) LineTables { double a[ON ? KCAP * vamp::TAB_LINE : 2]; };
 template <bool F32, int MODE, class PK>
 constexpr bool use_tables() { return PK::TABS && !F32 && MODE != VAMP_GAUSS3; }
+// wavefronts per SIMD the register allocation aims for: fp32 instructions issue in 2 cycles on a SIMD but one
+// wavefront can issue only every 4, so the fp32 form of the workgroup-per-walker shape wants MORE resident
+// wavefronts than the fp64 one (it has no Taylor tables: 12 KB of LDS per workgroup)
+template <bool F32, class PK>
+constexpr int min_waves() { return (F32 && PK::DTAB_IN_TABLES) ? VAMP_SPLIT_WAVES_F32 : PK::MIN_WAVES; }
 
 // the near-axis table of line k as the evaluators want it (unused by the table look-ups; not addressable
 // through L when it lives in the tables' space)
@@ -979,6 +987,8 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const typ
         const LineRec& me = L.line[kq];
         const unsigned long long farmask = ff_classify<4 * (int)sizeof(float)>(Sx, K, lane, me.c, me.w8, me.w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
+        // (VAMP_SKIP_*: timing-only builds of tools/variants.py -- the phase split in profiles/)
+#ifndef VAMP_SKIP_NEAR
         for (unsigned long long near = ~farmask & ((1ull << K) - 1ull); near; near &= near - 1ull) {
             const int k = __builtin_ctzll(near);
             const float c = L.linef[k][0], sc = L.linef[k][1], y = L.linef[k][2], a = L.linef[k][3];
@@ -989,14 +999,23 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const typ
 #pragma unroll
             for (int t = 0; t < T; ++t) tau[t] = fmaf(a, H[t], tau[t]);
         }
+#endif
         if (nfar > 0) {
+#ifndef VAMP_SKIP_FFNODES
             ff_coefficients<typename PK::Lds, true>(L, Sx, dct, lane, nfar, mid, half);
+#endif
+#ifndef VAMP_SKIP_CLENSHAW
             ff_horner<float, T>(Sx, xi, mid, half, x_hi > x_lo, tau);
+#endif
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int i = base + 64 * t + lane;
+#ifdef VAMP_SKIP_EXP
+            const float m = 1.0f - tau[t];
+#else
             const float m = __expf(-tau[t]);
+#endif
             const float r = (f[i] - m) * wt[i];
             chi += (double)r * (double)r;
         }
@@ -1221,7 +1240,7 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, typename PK::L
 // kernels
 // ---------------------------------------------------------------------------------------
 template <bool F32, int MODE, class PK>
-__global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
+__global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_lnprob(const RegionDev* __restrict__ regions, int region, PixPtrs px,
                                                   long long W, const double* __restrict__ theta,
                                                   double* __restrict__ lnprob, double* __restrict__ chi2,
                                                   const int* __restrict__ region_list) {
@@ -1456,7 +1475,7 @@ __global__ __launch_bounds__(256) void k_draws(SamplerDev S, unsigned step, int 
 // scalar-cache round trips); the headline shape measured 4.29 / 3.46 / 3.28 ms at 2 / 3 / 4 of them
 constexpr int DRAW_INLINE = 0, DRAW_HOST = 1, DRAW_PRE = 2;
 template <bool F32, int DRAWS, int MODE, class PK>
-__global__ __launch_bounds__(PK::THREADS, PK::MIN_WAVES) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
+__global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
                                                      long long ext_n, const int* __restrict__ ext_active,
                                                      const int* __restrict__ ext_partner, const double* __restrict__ ext_z,
                                                      const double* __restrict__ ext_logu, const double* __restrict__ ext_logz) {
@@ -1687,6 +1706,11 @@ struct vamp_ctx {
     int comm_rank = 0, comm_world = 1;
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> ev_kernel, ev_scatter;   // per part: kernel done / rows scattered
+    // exchange timing (vamp_exchange_timing): event pairs around all-gather + scatter on the stream they run on
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> xev;
+    size_t xev_used = 0;
+    double xtiming_ms = 0.0;
+    long long xtiming_n = 0;
     // grow-only scratch of vamp_lnprob (the MAP optimiser calls it thousands of times with W = 1)
     double *sc_th = nullptr, *sc_lp = nullptr, *sc_chi = nullptr;
     size_t sc_th_cap = 0, sc_w_cap = 0;
@@ -1749,10 +1773,49 @@ int flush_timing(vamp_ctx* c) {
     return 0;
 }
 
-// kernel shape of a launch of `n_walkers` walkers of class `cl`.  Never depends on the shard or
-// the entry point beyond the launch size rule of the packed shape (as in round 1: four walkers per
-// wavefront only pay off in launches that fill the chip), so a point has the same lnprob bits
-// through vamp_lnprob, vamp_lnprob_all and the sampler.
+int flush_exchange_timing(vamp_ctx* c) {
+    if (c->xev_used == 0) return 0;
+    HIP_TRY(hipEventSynchronize(c->xev[c->xev_used - 1].second));
+    for (size_t i = 0; i < c->xev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(c->xev[i].second));
+        HIP_TRY(hipEventElapsedTime(&ms, c->xev[i].first, c->xev[i].second));
+        c->xtiming_ms += ms;
+        c->xtiming_n += 1;
+    }
+    c->xev_used = 0;
+    return 0;
+}
+
+// exchange buffers of the shard set by vamp_sampler_set_shard_parts: the movers of every part in slot order,
+// position + lnprob per row (+ the per-part events when a communicator will run the exchange)
+int ensure_part_events(vamp_ctx* c, int parts);
+int alloc_exchange_buffers(vamp_ctx* c) {
+    const size_t row = (size_t)c->regions_h[0].D + 1;
+    HIP_TRY(hipMalloc(&c->send_d, (size_t)c->shard_parts * c->part_slots * row * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->recv_d, (size_t)c->shard_parts * c->shard_world * c->part_slots * row * sizeof(double)));
+    c->part_step.assign(c->shard_parts, 0u);
+    c->part_half.assign(c->shard_parts, 0);
+    if (c->comm) return ensure_part_events(c, c->shard_parts);
+    return 0;
+}
+
+// per-part events of the overlapped exchange (kernel of a part done / its rows scattered)
+int ensure_part_events(vamp_ctx* c, int parts) {
+    while ((int)c->ev_kernel.size() < parts) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        c->ev_kernel.push_back(a);
+        c->ev_scatter.push_back(b);
+    }
+    return 0;
+}
+
+// kernel shape of class `cl` for an ensemble of `n_walkers` movers per half-step.  `n_walkers` is the
+// UNSHARDED count (W/2 of a walker-sharded single-region ensemble, whatever this device's share or piece
+// of it), so that a shard runs the shape -- the same bits -- the whole ensemble runs on one device; the
+// packed shapes (several walkers per wavefront) only pay off for ensembles that fill the chip.
 int class_shape(const vamp_ctx* c, const LaunchClass& cl, long long n_walkers, bool packable) {
     if (cl.kind == CK_MID) return SH_MID;
     if ((cl.kind == CK_SMALL || cl.kind == CK_SMALL2) && packable && (c->packing == 16 || n_walkers >= PACK_MIN_WALKERS))
@@ -1865,7 +1928,8 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
             HIP_TRY(hipStreamWaitEvent(st, c->ev_fork, 0));
         }
         S.region_list = cl.list_d;
-        const int shape = class_shape(c, cl, n, packable);
+        // (a shard or a piece of a single-region ensemble takes the shape of the WHOLE ensemble)
+        const int shape = class_shape(c, cl, (!ext && c->n_regions == 1) ? halfW : n, packable);
         const unsigned grid = (unsigned)((n + shape_walkers_per_block(shape) - 1) / shape_walkers_per_block(shape));
         const dim3 threads(shape_threads(shape));
         if (ext) {
@@ -1921,6 +1985,8 @@ struct RcclApi {
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;        // optional: vamp_comm_info asks the communicator itself
+    int (*CommUserRank)(void*, int*) = nullptr;
     bool ok = false;
 };
 constexpr int RCCL_FLOAT64 = 8;       // ncclFloat64 / ncclDouble
@@ -1965,6 +2031,8 @@ int rccl_api(RcclApi** out) {
             api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
             api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
             api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+            api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
+            api.CommUserRank = (decltype(api.CommUserRank))dlsym(h, "ncclCommUserRank");
             api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
         }
     }
@@ -2014,12 +2082,32 @@ int exchange_part(vamp_ctx* c, int part) {
     const bool overlap = c->shard_parts > 1;
     hipStream_t st = overlap ? c->comm_stream : c->stream;
     if (overlap) {
+        rc = ensure_part_events(c, c->shard_parts);     // (whichever of set_shard_parts / comm_init_rank came first)
+        if (rc) return rc;
         HIP_TRY(hipEventRecord(c->ev_kernel[part], c->stream));
         HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_kernel[part], 0));
+    }
+    hipEvent_t x1 = nullptr;
+    if (c->timing) {
+        if (c->xev_used == c->xev.size()) {
+            if (c->xev.size() >= 4096) {
+                rc = flush_exchange_timing(c);
+                if (rc) return rc;
+            } else {
+                hipEvent_t a, b;
+                HIP_TRY(hipEventCreate(&a));
+                HIP_TRY(hipEventCreate(&b));
+                c->xev.emplace_back(a, b);
+            }
+        }
+        HIP_TRY(hipEventRecord(c->xev[c->xev_used].first, st));
+        x1 = c->xev[c->xev_used].second;
+        c->xev_used++;
     }
     RCCL_TRY(api, api->AllGather(send, recv, count, RCCL_FLOAT64, c->comm, st));
     rc = launch_scatter(c, part, st);
     if (rc) return rc;
+    if (x1) HIP_TRY(hipEventRecord(x1, st));
     if (overlap) HIP_TRY(hipEventRecord(c->ev_scatter[part], c->comm_stream));
     return 0;
 }
@@ -2111,6 +2199,10 @@ int vamp_ctx_destroy(vamp_ctx* c) {
     for (hipEvent_t e : c->ev_join) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (auto& p : c->ev) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    for (auto& p : c->xev) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
     }
@@ -2575,20 +2667,8 @@ int vamp_sampler_set_shard_parts(vamp_ctx* c, int rank, int world, int parts, in
     if (c->recv_d) (void)hipFree(c->recv_d);
     c->send_d = c->recv_d = nullptr;
     if (world > 1 || c->comm) {
-        const size_t row = (size_t)c->regions_h[0].D + 1;
-        HIP_TRY(hipMalloc(&c->send_d, (size_t)parts * c->part_slots * row * sizeof(double)));
-        HIP_TRY(hipMalloc(&c->recv_d, (size_t)parts * world * c->part_slots * row * sizeof(double)));
-        c->part_step.assign(parts, 0u);
-        c->part_half.assign(parts, 0);
-        if (c->comm) {
-            while ((int)c->ev_kernel.size() < parts) {
-                hipEvent_t a, b;
-                HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-                c->ev_kernel.push_back(a);
-                c->ev_scatter.push_back(b);
-            }
-        }
+        int rc = alloc_exchange_buffers(c);
+        if (rc) return rc;
     }
     for (int p = 0; p < parts; ++p) {
         const long long first = p * (chunks / parts) + rank * cpp;
@@ -2748,6 +2828,9 @@ int vamp_comm_init_rank(vamp_ctx* c, const char* id, int rank, int world) {
     if (!c || !id) return fail(VAMP_ERR_ARG, "vamp_comm_init_rank: NULL argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(VAMP_ERR_ARG, "vamp_comm_init_rank: bad rank/world");
     if (c->comm) return fail(VAMP_ERR_STATE, "vamp_comm_init_rank: the context already has a communicator");
+    // either order of vamp_sampler_set_shard_parts and vamp_comm_init_rank is accepted, but they must agree
+    if (c->sampler_ready && (c->shard_world != 1 || c->send_d) && (c->shard_world != world || c->shard_rank != rank))
+        return fail(VAMP_ERR_ARG, "vamp_comm_init_rank: rank/world differ from the shard already set (vamp_sampler_set_shard_parts)");
     RcclApi* api = nullptr;
     int rc = rccl_api(&api);
     if (rc) return rc;
@@ -2763,6 +2846,29 @@ int vamp_comm_init_rank(vamp_ctx* c, const char* id, int rank, int world) {
     c->comm_rank = rank;
     c->comm_world = world;
     HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    // the shard came first: its exchange buffers (a single-rank shard has none yet) and per-part events are due now
+    if (c->sampler_ready && c->n_regions == 1 && c->part_slots > 0) {
+        if (!c->send_d) rc = alloc_exchange_buffers(c);
+        else rc = ensure_part_events(c, c->shard_parts);
+        if (rc) return rc;
+    }
+    return VAMP_OK;
+}
+
+int vamp_comm_info(vamp_ctx* c, int* rank, int* world, int* queried) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_comm_info: ctx is NULL");
+    if (!c->comm) return fail(VAMP_ERR_STATE, "vamp_comm_info: the context has no communicator (vamp_comm_init_rank)");
+    int r = c->comm_rank, w = c->comm_world, q = 0;
+    RcclApi* api = nullptr;
+    if (rccl_api(&api) == 0 && api->CommCount && api->CommUserRank) {
+        int w2 = 0, r2 = 0;
+        RCCL_TRY(api, api->CommCount(c->comm, &w2));
+        RCCL_TRY(api, api->CommUserRank(c->comm, &r2));
+        r = r2; w = w2; q = 1;
+    }
+    if (rank) *rank = r;
+    if (world) *world = w;
+    if (queried) *queried = q;
     return VAMP_OK;
 }
 
@@ -2823,10 +2929,24 @@ int vamp_sampler_set_state(vamp_ctx* c, const double* theta, const double* lnpro
     return VAMP_OK;
 }
 
+int vamp_exchange_timing(vamp_ctx* c, double* total_ms, int64_t* exchanges) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_exchange_timing: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = flush_exchange_timing(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->xtiming_ms;
+    if (exchanges) *exchanges = c->xtiming_n;
+    c->xtiming_ms = 0.0;
+    c->xtiming_n = 0;
+    return VAMP_OK;
+}
+
 int vamp_kernel_timing(vamp_ctx* c, int enable, double* total_ms, int64_t* launches) {
     if (!c) return fail(VAMP_ERR_ARG, "vamp_kernel_timing: ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     int rc = flush_timing(c);
+    if (rc) return rc;
+    rc = flush_exchange_timing(c);
     if (rc) return rc;
     if (total_ms) *total_ms = c->timing_ms;
     if (launches) *launches = c->timing_launches;

@@ -145,11 +145,7 @@ class ShardedEnsemble:
             raise ValueError("W/split_block must be a multiple of ranks * parts")
         self.parts = parts
         if self.exchange == "rccl":
-            from .hip_backend import comm_unique_id
-            box = [comm_unique_id() if self.rank == 0 else None]
-            if self.world > 1:
-                dist.broadcast_object_list(box, src=0)        # 128 bytes over the bootstrap group
-            backend.comm_init_rank(box[0], self.rank, self.world)
+            self._join_communicator(backend, dist)
         backend.sampler_init(theta0, seed=seed, a=a, split_block=split_block)
         if self.world > 1 or self.parts > 1 or self.exchange == "rccl":
             self.own_ranges = backend.sampler_set_shard_parts(self.rank, self.world, self.parts)
@@ -161,6 +157,70 @@ class ShardedEnsemble:
         for b, e in self.own_ranges:
             self.own_mask[b:e] = True
         self.steps_done = 0
+
+    def _join_communicator(self, backend, dist):
+        """Every rank of ``dist`` ends this call with a communicator, or EVERY rank raises the same
+        VampError(-3): no rank is ever left alone inside a collective (bench.py's fall-back to the
+        host-staged exchange relies on that).
+          1. every rank checks locally that the RCCL entry points load and an id can be made; rank 0's
+             id and every rank's outcome travel over ``dist`` before anyone enters RCCL;
+          2. ncclCommInitRank blocks until all ranks have joined, so a rank that fails in it would
+             leave the others inside: the call runs in a thread that is given
+             ``VAMP_COMM_INIT_TIMEOUT`` seconds (default 300), and the outcomes are exchanged again.
+             A rank whose call never returned abandons its context (``backend.abandon()``) instead
+             of destroying it under the stuck call."""
+        import threading
+        from ._lib import VampError
+        from .hip_backend import comm_unique_id
+        have = getattr(backend, "comm", None)
+        if have is not None:                      # a re-built ensemble on a context that already joined
+            if have != (self.rank, self.world):
+                raise ValueError("the context's communicator has another rank/world")
+            return
+        err = None
+        try:
+            my_id = comm_unique_id(getattr(backend, "_lib", None))
+        except VampError as e:
+            my_id, err = None, str(e)
+        if self.world > 1:
+            box = [my_id if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)            # 128 bytes over the bootstrap group
+            my_id = box[0]
+            errs = [None] * self.world
+            dist.all_gather_object(errs, err)
+            bad = [(r, e) for r, e in enumerate(errs) if e]
+            if bad:
+                raise VampError(-3, "no RCCL communicator: rank %d: %s" % bad[0])
+        elif err:
+            raise VampError(-3, err)
+        out = {}
+
+        def join():
+            try:
+                backend.comm_init_rank(my_id, self.rank, self.world)
+            except Exception as e:                            # reported below, on every rank
+                out["err"] = str(e)
+
+        if self.world == 1:
+            join()
+            if "err" in out:
+                raise VampError(-3, out["err"])
+            return
+        timeout = float(os.environ.get("VAMP_COMM_INIT_TIMEOUT", "300"))
+        t = threading.Thread(target=join, daemon=True)
+        t.start()
+        t.join(timeout)
+        stuck = t.is_alive()
+        err = ("vamp_comm_init_rank did not return within %.0f s" % timeout) if stuck else out.get("err")
+        errs = [None] * self.world
+        dist.all_gather_object(errs, err)
+        bad = [(r, e) for r, e in enumerate(errs) if e]
+        if bad:
+            if stuck and hasattr(backend, "abandon"):
+                backend.abandon()
+            e = VampError(-3, "no RCCL communicator: rank %d: %s" % bad[0])
+            e.stuck = stuck
+            raise e
 
     def _exchange_host(self, p):
         """piece p: packed movers of every rank through host memory and ``dist``"""

@@ -31,11 +31,12 @@ def device_count():
     return n.value
 
 
-def comm_unique_id():
+def comm_unique_id(lib=None):
     """128-byte RCCL id for vamp_comm_init_rank: rank 0 creates it and sends it to the other
     ranks over any host channel."""
+    lib = lib if lib is not None else _lib.load()
     buf = C.create_string_buffer(128)
-    _lib.check(_lib.load().vamp_comm_unique_id(buf))
+    _lib.check(lib.vamp_comm_unique_id(buf), lib)
     return buf.raw
 
 
@@ -64,6 +65,7 @@ class HipContext:
         self.n_regions = 0
         self.ndims = []
         self.W = 0
+        self.comm = None          # (rank, world) once vamp_comm_init_rank has succeeded
 
     def _check(self, rc):
         _lib.check(rc, self._lib)
@@ -103,9 +105,23 @@ class HipContext:
         if len(comm_id) != 128:
             raise ValueError("comm_id must be the 128 bytes of comm_unique_id()")
         self._check(self._lib.vamp_comm_init_rank(self._h, C.c_char_p(bytes(comm_id)), int(rank), int(world)))
+        self.comm = (int(rank), int(world))
 
     def comm_destroy(self):
         self._check(self._lib.vamp_comm_destroy(self._h))
+        self.comm = None
+
+    def abandon(self):
+        """Drop the handle WITHOUT destroying the context: for a context another thread is still
+        inside (a vamp_comm_init_rank that never returned).  The memory is left to process exit."""
+        self._h = C.c_void_p()
+
+    def comm_info(self):
+        """(rank, world, queried): what the communicator reports through ncclCommUserRank /
+        ncclCommCount (queried = True), else the values it was created with."""
+        r, w, q = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self._lib.vamp_comm_info(self._h, C.byref(r), C.byref(w), C.byref(q)))
+        return r.value, w.value, bool(q.value)
 
     def pack_get(self, part=0):
         """This rank's movers of piece ``part`` after its last half-step: [slots, D + 1]
@@ -377,4 +393,12 @@ class HipContext:
         ms = C.c_double(0.0)
         n = C.c_int64(0)
         self._check(self._lib.vamp_kernel_timing(self._h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def exchange_timing(self):
+        """(ms, count) of the exchanges (all-gather + scatter of one piece) timed while
+        kernel_timing was on; resets."""
+        ms = C.c_double(0.0)
+        n = C.c_int64(0)
+        self._check(self._lib.vamp_exchange_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
