@@ -331,6 +331,23 @@ def make_q1422():
     print("q1422_spectrum.npz: %d pixels, %d regions" % (wl.size, len(px)))
 
 
+def make_q1422_vpm():
+    """vamp_1.0/data/q1422.vpm: the AutoVP-style line list of the SAME quasar spectrum that ships with the
+    reference (539 H I lines; no reference code reads it).  Data rows: index, N [1e12 cm^-2], velocity
+    [km/s], b [km/s], three error columns, a flag-like fraction, observed wavelength [A].  Stored as the
+    parsed doubles: a sanity yardstick for the end-to-end fit (another code's answer, not parity)."""
+    rows = []
+    for ln in open(os.path.join(REF, "data", "q1422.vpm")):
+        t = ln.split()
+        if len(t) == 9:
+            rows.append([float(v) for v in t[1:]])
+    a = np.array(rows)
+    assert a.shape == (539, 8)
+    np.savez_compressed(os.path.join(OUT, "q1422_vpm.npz"), N12=a[:, 0], velocity=a[:, 1], b=a[:, 2], err=a[:, 3:6],
+                        frac=a[:, 6], wavelength=a[:, 7])
+    print("q1422_vpm.npz: %d lines" % a.shape[0])
+
+
 def make_all(out_dir=None):
     """Write every fixture into ``out_dir`` (default: this directory)."""
     global OUT
@@ -344,6 +361,7 @@ def make_all(out_dir=None):
     make_lnprob_cases(simba)
     make_stretch(simba)
     make_q1422()
+    make_q1422_vpm()
 
 
 if __name__ == "__main__":

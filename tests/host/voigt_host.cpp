@@ -42,3 +42,18 @@ extern "C" void core_centre_host(int64_t n, const int* idx, const double* y, dou
         vamp::core_centre(idx[i], y[i], dtab, vamp::core_pole_factor(y[i]), vamp::core_hy(y[i]), re[i], im[i]);
     }
 }
+// H(x, y) through the per-line fp32 Taylor rows of fp32 contexts (x in [0, 8))
+extern "C" void voigt_H_table32_host(int64_t n, const double* x, const double* y, double* out) {
+    double dtab[vamp::DTAB_N];
+    float tab[vamp::TAB32_LINE];
+    double ylast = -1.0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (y[i] != ylast) {
+            for (int k = 0; k < vamp::DTAB_N; ++k) dtab[k] = vamp::core_dtab_entry(k, y[i]);
+            for (int r = 0; r < vamp::TAB_NI; ++r)
+                vamp::taylor_table_row32(r, y[i], dtab, vamp::core_pole_factor(y[i]), vamp::core_hy(y[i]), tab + r * vamp::TAB32_NT);
+            ylast = y[i];
+        }
+        out[i] = (double)vamp::taylor_table32_eval(tab, (float)fabs(x[i]));
+    }
+}

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -104,3 +105,16 @@ def test_c_client_runs(tmp_path):
     out = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "abi_client ok" in out.stdout
+
+
+def test_import_order_hazard_is_diagnosed():
+    """INTEGRATION.md "Two ROCm runtimes in one process": loading libvamp_hip.so before torch is
+    diagnosed with a RuntimeWarning (once, at load); torch first -- what bench.py and the tests do --
+    is silent.  (Loading needs no GPU.)"""
+    import subprocess
+    code = "import warnings; warnings.simplefilter('always'); %s import vamp_amd; vamp_amd._lib.load(); print('loaded')"
+    env = {k: v for k, v in os.environ.items() if k != "VAMP_NO_IMPORT_ORDER_WARNING"}
+    bad = subprocess.run([sys.executable, "-c", code % ""], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert bad.returncode == 0 and "loaded" in bad.stdout and "two ROCm runtimes" in bad.stderr
+    good = subprocess.run([sys.executable, "-c", code % "import torch;"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert good.returncode == 0 and "loaded" in good.stdout and "two ROCm runtimes" not in good.stderr

@@ -778,10 +778,13 @@ def test_full_size_dispersed_walkers_match_oracle(hip_ctx, grid):
     th = th.reshape(W, 4 * K)
     noise = np.full(P, 0.05)
     flux = np.clip(1.0 + rng.normal(0, 0.05, P), 0, None)
-    if grid == "descending":
-        x, flux, noise = x[::-1].copy(), flux[::-1].copy(), noise[::-1].copy()
-    hip_ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
+    # the oracle restates the reference, whose grids ascend (vpspectrum.py:274-277; bounds from x[0], x[-1]); the
+    # ABI takes either direction: the descending case uploads the mirrored arrays of the same region
     r = vo.Region(x=x, flux=flux, noise=noise, n_comp=K, mode=vo.MODE_VOIGT4)
+    if grid == "descending":
+        hip_ctx.set_regions(x[::-1].copy(), flux[::-1].copy(), noise[::-1].copy(), K, mode=vo.MODE_VOIGT4)
+    else:
+        hip_ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
     want = vo.log_prob_batch_fast(r, th)
     got = hip_ctx.lnprob(th)
     assert np.isfinite(want).all() and np.isfinite(got).all()

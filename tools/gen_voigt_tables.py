@@ -78,3 +78,45 @@ if __name__ == "__main__":
         print("// m =", m, " sum c =", float(sum(c for _, c in pf)))
         print("Z%d = {" % m + ", ".join("%.17e" % float(z) for z, _ in pf) + "}")
         print("C%d = {" % m + ", ".join("%.17e" % float(c) for _, c in pf) + "}")
+
+
+def economisation_matrix(n_keep, n_all, h=Fraction(1, 4)):
+    """Chebyshev economisation of a power series sum_{n < n_all} c_n d^n on |d| <= h down to degree n_keep - 1:
+    the powers d^(n_all-1) ... d^(n_keep) are replaced, highest first, by their best lower-degree stand-ins
+    (d^n = h^n [T_n(d/h) / 2^(n-1) - lower powers of d/h], T_n dropped).  Returns E with
+    c'_j = c_j + sum_n E[n - n_keep][j] c_n (exact rationals; entries of the other parity are 0)."""
+    def cheb(n):                    # coefficients of T_n(s), low -> high
+        a, b = [Fraction(1)], [Fraction(0), Fraction(1)]
+        if n == 0:
+            return a
+        for _ in range(n - 1):
+            c = [Fraction(0)] + [2 * v for v in b]
+            for i, v in enumerate(a):
+                c[i] -= v
+            a, b = b, c
+        return b
+    # M[n] = the series coefficients (over d^0 .. d^(n_all-1)) that c_n = 1 stands for
+    rows = []
+    for n0 in range(n_keep, n_all):
+        v = [Fraction(0)] * n_all
+        v[n0] = Fraction(1)
+        for n in range(n_all - 1, n_keep - 1, -1):
+            if v[n] == 0:
+                continue
+            t = cheb(n)
+            lead = t[n]                                   # 2^(n-1)
+            cn, v[n] = v[n], Fraction(0)
+            for k in range(n):
+                if t[k] != 0:
+                    v[k] -= cn * h ** (n - k) * t[k] / lead
+        rows.append(v[:n_keep])
+    return rows
+
+
+if __name__ == "__main__":
+    print("// TAB_ECON (fp64 tables: 18 -> 14 coefficients), by parity")
+    for n, row in zip(range(14, 18), economisation_matrix(14, 18)):
+        print("    {" + ", ".join("%.17e" % float(row[(n & 1) + 2 * m]) for m in range(7)) + "},")
+    print("// TAB32_ECON (fp32 tables: 12 -> 8 coefficients), by parity")
+    for n, row in zip(range(8, 12), economisation_matrix(8, 12)):
+        print("    {" + ", ".join("%.17e" % float(row[(n & 1) + 2 * m]) for m in range(4)) + "},")

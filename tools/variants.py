@@ -22,7 +22,9 @@ if sys.argv[1] == "build":
     for spec in sys.argv[2:]:
         name, _, flags = spec.partition("=")
         so = os.path.join(OUT, f"lib_{name}.so")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", so, SRC]
+        sys.path.insert(0, ROOT)
+        from vamp_amd.build import FLAGS                      # the product's own flags; NAME=-fslp-vectorize undoes one
+        cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", so, SRC]
         cmd += [f for f in flags.split(",") if f]
         procs.append((name, subprocess.Popen(cmd)))
     for name, p in procs:

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
+import warnings
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VAMP_HIP_LIB: developer knob to A/B alternative builds of the same ABI (tools/tier_cost.py)
@@ -87,8 +89,35 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built (run `python -c 'import "
             "__graft_entry__ as g; g.build()'`).  vamp_amd has no CPU fallback.")
+    _warn_if_loaded_before_torch()
     _lib = bind(LIB_PATH)
     return _lib
+
+
+loaded_before_torch = False
+
+
+def _warn_if_loaded_before_torch():
+    """INTEGRATION.md "Two ROCm runtimes in one process": a PyTorch wheel carries private copies of
+    libamdhip64 / libhsa-runtime64 / librccl.  Loaded AFTER torch, libvamp_hip.so binds to the runtime
+    torch already mapped and the process has one runtime; loaded BEFORE, it binds to /opt/rocm/lib and a
+    later `import torch` brings a second one, whose torch.cuda then fails to initialise ("No HIP GPUs are
+    available").  The library itself keeps working either way (its RCCL is the one beside the libamdhip64
+    it is bound to), so this is a diagnosis, not an error."""
+    global loaded_before_torch
+    if "torch" in sys.modules or os.environ.get("VAMP_NO_IMPORT_ORDER_WARNING"):
+        return
+    import importlib.util
+    try:
+        has_torch = importlib.util.find_spec("torch") is not None
+    except (ImportError, ValueError):
+        has_torch = False
+    if has_torch:
+        loaded_before_torch = True
+        warnings.warn("vamp_amd: libvamp_hip.so is being loaded before torch.  If this process imports torch later it will "
+                      "hold two ROCm runtimes and torch.cuda will not initialise: `import torch` first (INTEGRATION.md, "
+                      "\"Two ROCm runtimes in one process\"); VAMP_NO_IMPORT_ORDER_WARNING=1 silences this.", RuntimeWarning,
+                      stacklevel=3)
 
 
 class VampError(RuntimeError):

@@ -9,11 +9,19 @@ OUT = os.path.join(HERE, "libvamp_hip.so")
 DEPS = [SRC, os.path.join(HERE, "csrc", "ff_matrix.inc"), os.path.join(HERE, "csrc", "voigt_math.hpp"), os.path.join(HERE, "csrc", "map_search.hpp"), os.path.join(HERE, "..", "include", "vamp_hip.h")]
 
 
+# -fno-slp-vectorize: left to itself the SLP vectoriser pairs the independent fp32 chains of a lane's four pixels
+# into v_pk_fma_f32 / v_pk_mul_f32 and pays for the register pairing with v_mov (429 packed + 464 moves in the fp32
+# headline kernel).  On gfx950 a packed fp32 instruction issues no faster than its two halves, so this is pure
+# overhead: 2.699 -> 2.220 ms per half-step on the fp32 headline, fp64 unchanged (3.251 -> 3.239)
+# (profiles/r03_b_f32_variants.txt; MI355X_MICROARCH.md lists packed fp32 VALU as an anti-lever).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"]
+
+
 def build(force=False, verbose=True):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

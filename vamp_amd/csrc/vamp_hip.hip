@@ -141,6 +141,9 @@ template <int KCAP, bool OWN_DTAB> struct WalkerLds;
 #ifndef VAMP_SPLIT_WAVES_F32
 #define VAMP_SPLIT_WAVES_F32 4
 #endif
+#ifndef VAMP_F32_TABLES
+#define VAMP_F32_TABLES 1
+#endif
 template <int LPW_, int KCAP_, bool TAIL_, int WPB_, bool SPLIT_ = false, bool TABS_ = SPLIT_, bool FF_ = (LPW_ == 64)>
 struct Pack {
     static constexpr int LPW = LPW_, KCAP = KCAP_, SUBS = 64 / LPW_;
@@ -219,10 +222,21 @@ struct alignas(16) TileScratch {   // per wavefront: far-field working set of th
 };
 // Taylor tables of the near-axis zone of every line of ONE walker (voigt_math.hpp): 28 KiB, which
 // only a workgroup that serves a single walker can afford (4 workgroups per CU).
-template <bool ON, int KCAP = KMAX>
-struct alignas(16) LineTables { double a[ON ? KCAP * vamp::TAB_LINE : 2]; };
+template <int NDBL>
+struct alignas(16) LineTables { double a[NDBL]; };
 template <bool F32, int MODE, class PK>
 constexpr bool use_tables() { return PK::TABS && !F32 && MODE != VAMP_GAUSS3; }
+// fp32 contexts, workgroup-per-walker shape: the line cores through single-precision Taylor rows (voigt_math.hpp,
+// TAB32_*) instead of Humlicek's regions III / IV.  The space holds the rows of all KMAX lines (8 KB) followed by
+// the near-axis tables (5.6 KB of doubles) the rows' centre values are computed from.
+template <bool F32, int MODE, class PK>
+constexpr bool use_tables32() { return VAMP_F32_TABLES && PK::DTAB_IN_TABLES && F32 && MODE != VAMP_GAUSS3; }
+constexpr int TAB32_DOUBLES = KMAX * vamp::TAB32_LINE / 2;       // the float rows, counted in doubles
+template <bool F32, int MODE, class PK>
+constexpr int table_doubles() {
+    return use_tables<F32, MODE, PK>() ? PK::TAB_LINES * vamp::TAB_LINE
+           : use_tables32<F32, MODE, PK>() ? TAB32_DOUBLES + KMAX * vamp::DTAB_N : 2;
+}
 // wavefronts per SIMD the register allocation aims for: fp32 instructions issue in 2 cycles on a SIMD but one
 // wavefront can issue only every 4, so the fp32 form of the workgroup-per-walker shape wants MORE resident
 // wavefronts than the fp64 one (it has no Taylor tables: 12 KB of LDS per workgroup)
@@ -270,7 +284,7 @@ __device__ __forceinline__ double uniform_logp(double v, double lo, double hi, d
 // Turn theta (in LDS) into line records + prior.  Returns log-prior on every lane.
 // MODE is a compile-time parameter: one specialised kernel per parameterisation, no mode
 // branches in the staging code or in the pixel loop.
-template <int MODE, class PK = PackWide, bool TAB = false>
+template <int MODE, class PK = PackWide, bool TAB = false, bool TAB32 = false>
 __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::Lds& L, int lane, bool want_f32, int part,
                                               double* tab = nullptr) {
     // `lane` is the lane index inside the walker's group (0 .. LPW-1).  In a split workgroup
@@ -346,12 +360,14 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
     double (*dt)[vamp::DTAB_N];
     if constexpr (PK::DTAB_IN_TABLES && TAB)
         dt = reinterpret_cast<double (*)[vamp::DTAB_N]>(tab + PK::KCAP * vamp::TAB_LINE - PK::KCAP * vamp::DTAB_N);
+    else if constexpr (TAB32)
+        dt = reinterpret_cast<double (*)[vamp::DTAB_N]>(tab + TAB32_DOUBLES);     // behind the float rows
     else
         dt = L.dtab;
 #ifdef VAMP_SKIP_DTAB     // timing-only builds (tools/variants.py)
     if (false) {
 #else
-    if (MODE != VAMP_GAUSS3 && !want_f32) {
+    if (MODE != VAMP_GAUSS3 && (!want_f32 || TAB32)) {
 #endif
         constexpr int STEP = PK::SPLIT ? PK::THREADS : PK::LPW;
         for (int e = PK::SPLIT ? 64 * part + lane : lane; e < K * vamp::DTAB_N; e += STEP) {
@@ -384,6 +400,15 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
                                        tab + k * vamp::TAB_LINE + i * vamp::TAB_NT);
             }
         }
+        group_barrier<PK>();
+    }
+    if constexpr (TAB32) {
+        // fp32 rows: one (line, interval) pair per thread, centre values in double from the near-axis tables
+        static_assert(PK::SPLIT && KMAX * vamp::TAB_NI <= PK::THREADS, "one row per thread");
+        const int e = 64 * part + lane, k = e / vamp::TAB_NI, i = e % vamp::TAB_NI;
+        if (e < K * vamp::TAB_NI)
+            vamp::taylor_table_row32(i, L.line[k].y, dt[k], L.line[k].pole, L.line[k].hy,
+                                     reinterpret_cast<float*>(tab) + k * vamp::TAB32_LINE + i * vamp::TAB32_NT);
         group_barrier<PK>();
     }
     return lp;
@@ -917,6 +942,47 @@ __device__ __forceinline__ void tile_w4(float y, const float (&X)[T], float (&H)
     }
 }
 
+// the same with the line's fp32 Taylor rows for |z|^2 < 64 (the zone the far-field classification calls a line's
+// core): region I / II outside it (|z| >= 8 implies s >= 5.5), one table look-up per pixel inside
+__device__ __forceinline__ float table32_eval(const float* tab, float x) {
+    // interval i = floor(2 x) as round-to-nearest of 2 (x - 1/4): adding 2^23 + 2^22 leaves the integer in the low
+    // bits of the sum (no conversions); on a boundary either neighbour is right (|d| = 1/4 in both)
+    constexpr float MAGIC = 12582912.0f;
+    const float xs = x - 0.25f;
+    const float t = fmaf(xs, 2.0f, MAGIC);
+    const int i = __float_as_int(t) & 15;
+    const float d = fmaf(t - MAGIC, -0.5f, xs);
+    const float4* a = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + i * (vamp::TAB32_NT * (int)sizeof(float)));
+    const float4 lo = a[0], hi = a[1];
+    float r = fmaf(hi.w, d, hi.z);
+    r = fmaf(r, d, hi.y);
+    r = fmaf(r, d, hi.x);
+    r = fmaf(r, d, lo.w);
+    r = fmaf(r, d, lo.z);
+    r = fmaf(r, d, lo.y);
+    return fmaf(r, d, lo.x);
+}
+template <int T>
+__device__ __forceinline__ void tile_w4_tab(float y, const float (&X)[T], float (&H)[T], const float* tab) {
+    float lo = X[0];
+#pragma unroll
+    for (int t = 1; t < T; ++t) lo = fminf(lo, X[t]);
+    const float y2 = y * y;
+    if (!__any(!(lo + y >= 15.0f))) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) H[t] = vamp::w4_region1(X[t], y);
+    } else if (!__any(!(fmaf(lo, lo, y2) >= (float)vamp::R2_CORE))) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) H[t] = vamp::w4_region2(X[t], y);
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (fmaf(X[t], X[t], y2) < (float)vamp::R2_CORE) H[t] = table32_eval(tab, X[t]);
+            else H[t] = vamp::w4_region2(X[t], y);
+        }
+    }
+}
+
 template <int MODE, class PK, int T>
 __device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const typename PK::Lds& L, const float* __restrict__ x,
                                                 const float* __restrict__ f, const float* __restrict__ wt, int lane,
@@ -964,11 +1030,11 @@ __device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const typena
 // fp32 sweep of full tiles with the far field: near lines through W4 in fp32, all far lines through
 // the tile's interpolant -- node values and cosine transform in fp64 (one evaluation per lane,
 // same code as the fp64 path), transform in fp64, Horner per pixel in fp32.
-template <int MODE, class PK>
+template <int MODE, class PK, bool TAB32>
 __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const typename PK::Lds& L, TileScratch& Sx,
                                                    const double* __restrict__ dct, const float* __restrict__ x,
                                                    const float* __restrict__ f, const float* __restrict__ wt, int lane,
-                                                   int base0, int base1, int stride, double& chi) {
+                                                   int base0, int base1, int stride, double& chi, const float* tab32) {
     constexpr int T = TPIX;
     static_assert(PK::LPW == 64 && PK::KCAP <= 16 && MODE != VAMP_GAUSS3, "far-field tiles: one walker per wavefront, Voigt lines");
     const int K = R.K;
@@ -995,7 +1061,8 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const typ
             float X[T], H[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) X[t] = fabsf(xi[t] - c) * sc;
-            tile_w4<T>(y, X, H);
+            if constexpr (TAB32) tile_w4_tab<T>(y, X, H, tab32 + k * vamp::TAB32_LINE);
+            else tile_w4<T>(y, X, H);
 #pragma unroll
             for (int t = 0; t < T; ++t) tau[t] = fmaf(a, H[t], tau[t]);
         }
@@ -1039,7 +1106,8 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const typename P
     if constexpr (F32) {
         const float* x = px.xf + R.pix_off; const float* f = px.ff + R.pix_off; const float* wt = px.wtf + R.pix_off;
         if constexpr (VAMP_FARFIELD && PK::FF && MODE != VAMP_GAUSS3 && TPIX == 4)
-            sweep_range_f32_ff<MODE, PK>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi);
+            sweep_range_f32_ff<MODE, PK, use_tables32<F32, MODE, PK>()>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi,
+                                                                        reinterpret_cast<const float*>(tab));
         else if (TPIX > 1) sweep_range_f32<MODE, PK, TPIX>(R, L, x, f, wt, lane, base0, full, stride, chi);
         if constexpr (PK::TAIL || TPIX == 1)
             if (tail) {
@@ -1220,7 +1288,8 @@ __device__ __forceinline__ double loglike_from_sum(const RegionDev& R, const LDS
 template <bool F32, int MODE, class PK = PackWide>
 __device__ __forceinline__ double wave_lnprob(const RegionDev& R, typename PK::Lds& L, TileScratch& Sx, const double* dct,
                                               const PixPtrs& px, int lane, double* chi_out, int part, double* red, double* tab) {
-    const double lp = stage_lines<MODE, PK, use_tables<F32, MODE, PK>() && PK::LINES_PER_PASS == 0>(R, L, lane, F32, part, tab);
+    const double lp = stage_lines<MODE, PK, use_tables<F32, MODE, PK>() && PK::LINES_PER_PASS == 0, use_tables32<F32, MODE, PK>()>(
+        R, L, lane, F32, part, tab);
     if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
         if (chi_out) *chi_out = __builtin_nan("");
         return NEG_INF;
@@ -1253,7 +1322,7 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_lnprob(
     __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
     __shared__ alignas(16) double dct[PK::FF ? FF_TABLE : 1];
     __shared__ double red[PARTS];
-    __shared__ LineTables<use_tables<F32, MODE, PK>(), PK::TAB_LINES> tabs[PK::SPLIT ? 1 : PK::WPB];
+    __shared__ LineTables<table_doubles<F32, MODE, PK>()> tabs[PK::SPLIT ? 1 : PK::WPB];
     if constexpr (PK::FF) ff_fill_table(dct);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
@@ -1484,7 +1553,7 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_st
     __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
     __shared__ alignas(16) double dct[PK::FF ? FF_TABLE : 1];
     __shared__ double red[PARTS];
-    __shared__ LineTables<use_tables<F32, MODE, PK>(), PK::TAB_LINES> tabs[PK::SPLIT ? 1 : PK::WPB];
+    __shared__ LineTables<table_doubles<F32, MODE, PK>()> tabs[PK::SPLIT ? 1 : PK::WPB];
     if constexpr (PK::FF) ff_fill_table(dct);
     const int lane = threadIdx.x & 63;
     // the wave index is the same in every lane: say so, and the draws below (Philox rounds, the
@@ -2046,6 +2115,55 @@ int rccl_api(RcclApi** out) {
         if (r_ != 0) return fail(VAMP_ERR_COMM, std::string(#expr) + ": " + (api)->GetErrorString(r_)); \
     } while (0)
 
+// ---- roctx ranges (SURVEY section 5 "Tracing"), bound at run time like RCCL ----------------------
+// `rocprofv3 --marker-trace` shows the sampler loop, every half-step (with its exchange), the MAP searches and
+// the batched evaluations as named ranges around the kernels.  Without a tool attached a range costs two calls
+// into an idle library; VAMP_ROCTX=0 switches them off altogether.
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+RoctxApi* roctx_api() {
+    static RoctxApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* sw = getenv("VAMP_ROCTX");
+        if (sw && std::atoi(sw) == 0) return nullptr;
+        std::vector<std::string> names;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t cut = dir.rfind('/');
+            if (cut != std::string::npos) {
+                dir.resize(cut);
+                names.push_back(dir + "/librocprofiler-sdk-roctx.so.1");
+                names.push_back(dir + "/libroctx64.so.4");
+            }
+        }
+        for (const char* n : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1",
+                              "/opt/rocm/lib/libroctx64.so.4"})
+            names.push_back(n);
+        for (const std::string& name : names) {
+            void* h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!h) continue;
+            api.push = (decltype(api.push))dlsym(h, "roctxRangePushA");
+            api.pop = (decltype(api.pop))dlsym(h, "roctxRangePop");
+            if (api.push && api.pop) break;
+            api.push = nullptr;
+            api.pop = nullptr;
+        }
+    }
+    return (api.push && api.pop) ? &api : nullptr;
+}
+struct RoctxRange {
+    RoctxApi* a;
+    explicit RoctxRange(const char* name) : a(roctx_api()) { if (a) a->push(name); }
+    ~RoctxRange() { if (a) a->pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 // rows of part `part` gathered in c->recv_d -> walker rows (on `st`)
 int launch_scatter(vamp_ctx* c, int part, hipStream_t st) {
     SamplerDev S;
@@ -2114,6 +2232,7 @@ int exchange_part(vamp_ctx* c, int part) {
 
 // one half-step of this device's whole share; with a communicator, followed by the exchange
 int half_step_all(vamp_ctx* c, int half) {
+    RoctxRange range(half ? "vamp half-step 1 (blue moves)" : "vamp half-step 0 (red moves)");
     for (int p = 0; p < c->shard_parts; ++p) {
         int rc = launch_half(c, half, false, 0, 0, p);
         if (rc) return rc;
@@ -2474,6 +2593,7 @@ int vamp_lnprob_all(vamp_ctx* c, int64_t W, const double* theta, double* lnprob,
     if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_lnprob_all: call vamp_set_regions first");
     if (W <= 0) return fail(VAMP_ERR_ARG, "vamp_lnprob_all: W must be positive");
     if (c->n_regions > 65535) return fail(VAMP_ERR_ARG, "vamp_lnprob_all: at most 65535 regions per launch");
+    RoctxRange range("vamp_lnprob_all");
     return lnprob_impl(c, -1, W, theta, lnprob, chi2);
 }
 
@@ -2484,6 +2604,7 @@ int vamp_map_all(vamp_ctx* c, const double* theta0, const uint8_t* active, int64
     if (c->n_regions > 65535) return fail(VAMP_ERR_ARG, "vamp_map_all: at most 65535 regions per launch");
     if (maxiter < 0 || maxfun < 0 || !(xtol >= 0.0) || !(ftol >= 0.0)) return fail(VAMP_ERR_ARG, "vamp_map_all: bad limits");
     // the searches themselves: csrc/map_search.hpp (scipy fmin's rules; shared with the host build of this ABI)
+    RoctxRange range("vamp_map_all");
     std::vector<int> dims(c->n_regions);
     std::vector<long long> offs(c->n_regions);
     for (int r = 0; r < c->n_regions; ++r) {
@@ -2596,6 +2717,7 @@ int vamp_sampler_init(vamp_ctx* c, int64_t W, const double* theta0, uint64_t see
     if (split_block < 2 || (split_block & 1) || W % split_block) return fail(VAMP_ERR_ARG, "vamp_sampler_init: split_block must be even and divide W");
     if (!(a > 1.0)) return fail(VAMP_ERR_ARG, "vamp_sampler_init: a must be > 1");
     HIP_TRY(hipSetDevice(c->device));
+    RoctxRange range("vamp_sampler_init");
     HIP_TRY(hipStreamSynchronize(c->stream));
     long long tt = 0;
     for (int r = 0; r < c->n_regions; ++r) {
@@ -2763,6 +2885,7 @@ int vamp_sampler_run_dev(vamp_ctx* c, int64_t n_steps, int thin, double* chain_d
         return fail(VAMP_ERR_STATE, "vamp_sampler_run_dev: a sharded context without a communicator is stepped by the host "
                                     "(half_step_part + pack_get / scatter_put)");
     HIP_TRY(hipSetDevice(c->device));
+    RoctxRange range("vamp_sampler_run");
     const long long n_keep = n_steps / thin;
     HIP_TRY(hipStreamSynchronize(c->stream));
     const auto t0 = std::chrono::steady_clock::now();

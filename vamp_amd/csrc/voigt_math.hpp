@@ -505,6 +505,66 @@ VAMP_DEV void taylor_table_row_from_centre(int i, double y, double c0r, double c
 #endif
 }
 
+// ---- fp32 contexts: the same tables in single precision -------------------------------------------
+// Humlicek's W4 costs ~25 instructions per evaluation in its regions I / II but ~45 (III) and ~120 (IV: a
+// 7/7 complex rational plus exp and cos) in the line cores, where every near (line, tile) pair of the
+// headline lies: 44 % of the fp32 kernel.  The cores therefore take the fp64 path's route -- per-line
+// Taylor rows on |x| < 8, built once per walker from the same centre values (core_centre) by the same
+// recurrence -- truncated to what single precision can hold: TAB32_NC = 12 Taylor coefficients
+// (|c_12| (1/4)^12 < 3e-9, Cauchy estimate on a circle of radius 2), economised on |d| <= 1/4 to TAB32_NT = 8
+// (error < 1e-7 of the line centre), scaled by 1/sqrt(pi) so that a row returns H like W4 does, stored as
+// floats: 32 B per row, one evaluation = index, two 16-byte LDS reads, 7 fp32 multiply-adds.  Against
+// scipy's wofz the rows are ~1000 x closer than W4 (tests/test_oracle.py::test_taylor_tables32_host_build);
+// W4 remains the evaluator of the wings (regions I / II), of short regions and of vamp_wofz_re.
+constexpr int TAB32_NC = 12;
+constexpr int TAB32_NT = 8;
+constexpr int TAB32_LINE = TAB_NI * TAB32_NT;   // floats per line
+constexpr double TAB32_ECON[4][4] = {            // tools/gen_voigt_tables.py: economisation_matrix(8, 12)
+    {-1.19209289550781250e-07, 6.10351562500000000e-05, -4.88281250000000000e-03, 1.25000000000000000e-01},
+    {-5.36441802978515625e-07, 1.14440917968750000e-04, -6.59179687500000000e-03, 1.40625000000000000e-01},
+    {-1.67638063430786133e-08, 8.04662704467773438e-06, -5.72204589843750000e-04, 1.09863281250000000e-02},
+    {-8.19563865661621094e-08, 1.63912773132324219e-05, -8.39233398437500000e-04, 1.34277343750000000e-02}};
+VAMP_DEV void taylor_table_row32_from_centre(int i, double y, double c0r, double c0i, float* out) {
+    const double zr = (i + 0.5) * CORE_H, zi = y;
+    double c1r = -2.0 * (zr * c0r - zi * c0i);
+    double c1i = fma(-2.0, fma(zr, c0i, zi * c0r), 2.0);
+    double cr[TAB32_NC];
+    cr[0] = c0r;
+    cr[1] = c1r;
+#pragma unroll
+    for (int n = 1; n + 1 < TAB32_NC; ++n) {
+        const double f = -2.0 / (double)(n + 1);
+        const double nr = f * (fma(zr, c1r, -zi * c1i) + c0r);
+        const double ni = f * (fma(zr, c1i, zi * c1r) + c0i);
+        c0r = c1r; c0i = c1i;
+        c1r = nr; c1i = ni;
+        cr[n + 1] = nr;
+    }
+#pragma unroll
+    for (int n = TAB32_NT; n < TAB32_NC; ++n) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cr[(n & 1) + 2 * m] = fma(TAB32_ECON[n - TAB32_NT][m], cr[n], cr[(n & 1) + 2 * m]);
+    }
+#pragma unroll
+    for (int n = 0; n < TAB32_NT; ++n) out[n] = (float)(INV_SQRT_PI * cr[n]);
+}
+VAMP_DEV void taylor_table_row32(int i, double y, const double* dtab, double pole, double hy, float* out) {
+    double c0r, c0i;
+    core_centre(i, y, dtab, pole, hy, c0r, c0i);
+    taylor_table_row32_from_centre(i, y, c0r, c0i, out);
+}
+// H(x, y) for 0 <= x < 8 from the line's fp32 table
+VAMP_DEV float taylor_table32_eval(const float* tab, float x) {
+    int i = (int)(x * 2.0f);
+    i = i < TAB_NI - 1 ? i : TAB_NI - 1;
+    const float d = fmaf((float)i, -(float)CORE_H, x) - 0.5f * (float)CORE_H;
+    const float* a = tab + i * TAB32_NT;
+    float r = a[TAB32_NT - 1];
+#pragma unroll
+    for (int n = TAB32_NT - 2; n >= 0; --n) r = fmaf(r, d, a[n]);
+    return r;
+}
+
 // the same from the line's near-axis table
 VAMP_DEV void taylor_table_row(int i, double y, const double* dtab, double pole, double hy, double* out) {
     double c0r, c0i;

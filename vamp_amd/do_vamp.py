@@ -45,12 +45,35 @@ def plan_workers(files, parallel, gpus):
     return [(r % max(1, int(gpus)), files[r::n]) for r in range(n)]
 
 
+def perf_record(spec, path, seconds, batched):
+    """One JSON-able record per fitted spectrum (SURVEY section 5 "Metrics / logging": the reference only
+    prints; its one timing is VPfit.fit_time, vpfits.py:392-395, kept here per region)."""
+    import numpy as np
+    regs = getattr(spec, "regions", [])
+    chi = np.array([r.best_chi_squared for r in regs], dtype=float)
+    fit_s = [float(getattr(r.fit, "fit_time", 0.0) or 0.0) for r in regs]
+    return {"spectrum": os.path.basename(str(path)), "regions": len(regs), "lines": int(sum(r.n for r in regs)),
+            "pixels_in_regions": int(sum(r.num_pixels for r in regs)), "seconds": float(seconds), "batched": bool(batched),
+            "sampler_seconds_last_fits": float(sum(fit_s)), "median_reduced_chi2": float(np.median(chi)) if chi.size else None,
+            "frac_regions_below_chi_limit": float(np.mean(chi < spec.chi_limit)) if chi.size else None,
+            "difficult_fit": bool(spec.flux_model.get("difficult_fit", False)), "voigt": bool(spec.voigt)}
+
+
 def fit_one(path, args, device=0):
+    import json
+    import time
     from .vpspectrum import VPspectrum
     spec = VPspectrum(args.line, path, args.output_folder, voigt=args.voigt, chi_limit=1.5, mcmc_cov=False,
                       get_mcmc_err=True, convergence_attempts=args.conv_attempts, nwalkers=args.walkers,
                       iterations=args.iterations, thin=args.thin, burn=args.burn, seed=args.seed)
-    return spec.fit_spectrum(batched=args.batched)
+    t0 = time.perf_counter()
+    params = spec.fit_spectrum(batched=args.batched)
+    rec = perf_record(spec, path, time.perf_counter() - t0, args.batched)
+    print("vamp_perf " + json.dumps(rec), flush=True)
+    if args.output_folder is not None and getattr(spec, "output_filename", None):
+        with open(spec.output_filename + "perf.json", "w") as fh:
+            json.dump(rec, fh)
+    return params
 
 
 def _worker(device, files, args, fit_name):

@@ -122,6 +122,8 @@ def detection_regions(wavelength, flux, noise, min_region_width=2, N_sigma=4.0, 
     return pixels, waves
 
 
+BATCH_MAX_LINES = 8          # lines per region in a ragged batch (vamp_amd/batched.py: the packed launch shapes)
+
 class VPspectrum():
 
     def __init__(self, line, spectrum_file=None, out_folder=None, voigt=False, chi_limit=1.5, mcmc_cov=False,
@@ -209,8 +211,9 @@ class VPspectrum():
         """Detect regions, fit each (retrying up to ``convergence_attempts`` times, keeping the best
         reduced chi^2), harvest N, b, EW, centres and their errors (vpspectrum.py:243-442).
         Returns the ``params`` dict.  ``batched=True`` runs the BIC ladders of all regions together
-        (one kernel launch per half-step for the whole spectrum, vamp_amd/batched.py; one attempt
-        per region)."""
+        (one kernel launch per half-step for the whole spectrum, vamp_amd/batched.py) with the same
+        retry / keep-best loop over the regions still above the chi^2 limit; regions that want more
+        lines than a batch holds (8) are fitted one by one as the reference does."""
         self.compute_detection_regions(min_region_width=2)
         self.split_difficult_region()
         if batched:
@@ -226,31 +229,7 @@ class VPspectrum():
         for j, (start, end) in enumerate(self.region_pixels):
             waves = np.flip(self.wavelength_array[start:end], 0)
             region = self._region(start, end)
-            fluxes, noise = region.flux_array, region.noise_array
-            attempts = self.convergence_attempts
-            if region.n > self.max_single_region_components:           # vpspectrum.py:287-294
-                attempts = 1 if region.n > 1.5 * self.max_single_region_components else 2
-                self.flux_model['difficult_fit'] = True
-            best_chi, best_fit = -1.0, None
-            tried_n, tried_chi = [], []
-            for _ in range(attempts):
-                region.estimate_n()
-                # after three poor fits with the same n, force one more component (intent of :306-321)
-                while tried_n.count(region.n) > 2 and \
-                        min(c for n_, c in zip(tried_n, tried_chi) if n_ == region.n) > self.chi_sq_maximum:
-                    region.n += 1
-                limit = region.chi_limit * 3 if region.n > self.max_single_region_components else region.chi_limit
-                region.region_fit(verbose=self.verbose, iterations=self.iterations, thin=self.thin, burn=self.burn)
-                region.set_freedom()
-                chi = region.fit.ReducedChisquared(fluxes, region.fit.total.value, noise, region.freedom)
-                tried_n.append(region.n)
-                tried_chi.append(chi)
-                if self.verbose:
-                    print('Reduced chi squared is {:.2f}'.format(chi))
-                if best_fit is None or chi < best_chi:
-                    best_chi, best_fit = chi, region.fit
-                if best_chi < limit:
-                    break
+            best_chi, best_fit = self._fit_region_attempts(region)
             region.fit = best_fit
             region.best_chi_squared = best_chi
             region.n = len(region.fit.estimated_profiles)
@@ -264,6 +243,38 @@ class VPspectrum():
             self.write_file()
         return self.params
 
+    def _fit_region_attempts(self, region):
+        """The reference's per-region retry loop (vpspectrum.py:281-348): up to ``convergence_attempts``
+        fits, keeping the best reduced chi^2; a region that wants more than
+        ``max_single_region_components`` lines is flagged ``difficult_fit``, gets 2 attempts (1 beyond
+        1.5 x that number) and three times the chi^2 limit.  Returns (best reduced chi^2, its fit)."""
+        fluxes, noise = region.flux_array, region.noise_array
+        attempts = self.convergence_attempts
+        if region.n > self.max_single_region_components:           # vpspectrum.py:287-294
+            attempts = 1 if region.n > 1.5 * self.max_single_region_components else 2
+            self.flux_model['difficult_fit'] = True
+        best_chi, best_fit = -1.0, None
+        tried_n, tried_chi = [], []
+        for _ in range(attempts):
+            region.estimate_n()
+            # after three poor fits with the same n, force one more component (intent of :306-321)
+            while tried_n.count(region.n) > 2 and \
+                    min(c for n_, c in zip(tried_n, tried_chi) if n_ == region.n) > self.chi_sq_maximum:
+                region.n += 1
+            limit = region.chi_limit * 3 if region.n > self.max_single_region_components else region.chi_limit
+            region.region_fit(verbose=self.verbose, iterations=self.iterations, thin=self.thin, burn=self.burn)
+            region.set_freedom()
+            chi = region.fit.ReducedChisquared(fluxes, region.fit.total.value, noise, region.freedom)
+            tried_n.append(region.n)
+            tried_chi.append(chi)
+            if self.verbose:
+                print('Reduced chi squared is {:.2f}'.format(chi))
+            if best_fit is None or chi < best_chi:
+                best_chi, best_fit = chi, region.fit
+            if best_chi < limit:
+                break
+        return best_chi, best_fit
+
     def _fit_spectrum_batched(self):
         from .batched import BatchedRegionLadder
         empty = lambda: np.array([])
@@ -274,34 +285,55 @@ class VPspectrum():
                            'centers': empty(), 'region_numbers': empty(), 'EW': np.zeros(nreg), 'std_a': empty(),
                            'std_s': empty(), 'std_c': empty(), 'cov_as': empty(), 'difficult_fit': self.difficult_fit}
         self.regions = [self._region(s, e) for s, e in self.region_pixels]
-        # the reference's retry loop (vpspectrum.py:297-348), for all regions at once: every attempt
-        # re-estimates n and runs the ladder of the regions whose best reduced chi^2 is still above
-        # the limit, with fresh draws; a region keeps the best fit it has seen
+        # the reference's retry loop (vpspectrum.py:281-348) for all regions at once: every attempt re-estimates n
+        # and runs the ladder of the regions whose best reduced chi^2 is still above their limit, with fresh
+        # draws; a region keeps the best fit it has seen.  Two batches, by the launch shapes they run on: regions
+        # that want <= BATCH_MAX_LINES lines (the packed shapes of real spectra) and the few that want more (a
+        # wavefront per walker, up to the kernels' 16 lines) -- those are NOT clamped to 8 and retried against an
+        # unscaled limit: as in the reference a region beyond max_single_region_components is flagged
+        # difficult_fit, gets 2 attempts (1 beyond 1.5 x) and three times the chi^2 limit (:287-294, 325-327)
+        from .batched import MAX_COMPONENTS
         best = {}
-        pending = list(range(nreg))
+        small, big = [], []
+        for i, r in enumerate(self.regions):
+            r.estimate_n()
+            (big if r.n > BATCH_MAX_LINES else small).append(i)
         ctx = None
-        for attempt in range(max(1, int(self.convergence_attempts))):
-            regs = [self.regions[i] for i in pending]
-            for r in regs:
-                r.estimate_n()
-                r.n = min(r.n, 8)       # ragged batches keep to 8 lines per region (four walkers per wavefront)
-            ladder = BatchedRegionLadder(regs, nwalkers=self.nwalkers or 64, iterations=self.iterations, thin=self.thin,
-                                         burn=self.burn, seed=(self.seed or 0) + 7727 * attempt, verbose=self.verbose, ctx=ctx)
-            ctx = ladder.ctx
-            ladder.run()
-            still = []
-            for i, region in zip(pending, regs):
-                region.set_freedom()
-                chi = region.fit.ReducedChisquared(region.flux_array, region.fit.total.value, region.noise_array, region.freedom)
-                if i not in best or chi < best[i][0]:
-                    best[i] = (chi, region.fit)
-                if not (best[i][0] < region.chi_limit):
-                    still.append(i)
-            if self.verbose:
-                print("attempt {}: {} of {} regions above the chi^2 limit".format(attempt + 1, len(still), nreg))
-            pending = still
-            if not pending:
-                break
+        for group, cap in ((small, BATCH_MAX_LINES), (big, MAX_COMPONENTS)):
+            left = {}
+            for i in group:
+                n0 = self.regions[i].n
+                left[i] = max(1, int(self.convergence_attempts))
+                if n0 > self.max_single_region_components:
+                    left[i] = 1 if n0 > 1.5 * self.max_single_region_components else 2
+                    self.flux_model['difficult_fit'] = True
+                    if self.verbose:
+                        print("region {}: {} lines estimated: difficult fit ({} attempt(s), 3 x the chi^2 limit)".format(i, n0, left[i]))
+            pending, attempt = list(group), 0
+            while pending:
+                regs = [self.regions[i] for i in pending]
+                for r in regs:
+                    r.estimate_n()
+                    r.n = min(r.n, cap)
+                ladder = BatchedRegionLadder(regs, nwalkers=self.nwalkers or 64, iterations=self.iterations, thin=self.thin,
+                                             burn=self.burn, seed=(self.seed or 0) + 7727 * attempt + (0 if cap == BATCH_MAX_LINES else 15485863),
+                                             verbose=self.verbose, ctx=ctx)
+                ctx = ladder.ctx
+                ladder.run()
+                still = []
+                for i, region in zip(pending, regs):
+                    region.set_freedom()
+                    chi = region.fit.ReducedChisquared(region.flux_array, region.fit.total.value, region.noise_array, region.freedom)
+                    if i not in best or chi < best[i][0]:
+                        best[i] = (chi, region.fit)
+                    limit = region.chi_limit * 3 if region.n > self.max_single_region_components else region.chi_limit
+                    left[i] -= 1
+                    if not (best[i][0] < limit) and left[i] > 0:
+                        still.append(i)
+                attempt += 1
+                if self.verbose:
+                    print("attempt {} (<= {} lines): {} of {} regions go again".format(attempt, cap, len(still), len(group)))
+                pending = still
         if ctx is not None:
             ctx.close()
         for j, ((start, end), region) in enumerate(zip(self.region_pixels, self.regions)):
