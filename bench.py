@@ -274,9 +274,32 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
-# fp64 VALU issue roof of one MI355X: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (one DFMA per lane and clock)
+# VALU issue roof of one MI355X: 256 CUs x 4 SIMDs x 2.4 GHz x 16 lanes per clock in fp64 (a wave instruction holds
+# its SIMD for 4 cycles), 32 lanes per clock in fp32 (2 cycles; one wavefront alone can issue only every 4, so the
+# fp32 roof needs >= 2 ready wavefronts per SIMD) -- MI355X_MICROARCH.md: 78.6 / 157.3 TFLOP/s vector peaks
 VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9
+VALU_PEAK_LANE_INSTR_F32 = 256 * 4 * 32 * 2.4e9
 FP64_PEAK_TFLOPS = 2.0 * VALU_PEAK_LANE_INSTR / 1e12          # 78.6 (an FMA counts two)
+
+
+def committed_pmc(P, K, W, D, world, dtype, workload="headline"):
+    """Counters of THIS command from the committed PMC passes (profiles/pmc_traffic*.json; tools/pmc.sh runs them
+    as separate rocprofv3 --pmc passes, tools/make_pmc_json.py condenses them), or None when no file matches."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic*.json"))):
+        try:
+            pj = json.load(open(path))
+            c = pj["config"]
+            if c.get("workload", "headline") != workload or c["dtype"] != dtype or c["n_gpus"] != world or c["walkers"] != W:
+                continue
+            if workload == "headline" and (c["pixels"], c["components"], c["ndim"]) != (P, K, D):
+                continue
+            return pj
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 # builder-counted arithmetic of ONE direct evaluation (DESIGN.md section 3 "flop count"):
 # F_w  = flops of sqrt(pi) Re w(z) incl. forming z and the tau FMA, averaged over this workload's mix of
 #        branches when every (pixel, line) pair is evaluated directly (build e: 45.6 VALU instructions per
@@ -509,16 +532,13 @@ def main():
         per_launch_units = own // (2 * ens.parts)       # walker-steps of one half-step launch on this rank
         avg_ms = k_ms / max(1, k_n)
         traffic = valu_instr = valu_busy = pmc_src = None
-        try:      # counters of this same command from the committed PMC passes (tools/pmc.sh; separate runs)
-            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            c = pj["config"]
-            if dist is None and (c["pixels"], c["components"], c["walkers"], c["ndim"], c["n_gpus"], c["dtype"]) == (P, K, W, D, world, args.dtype):
-                traffic = (2.0 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024.0
-                valu_instr = pj.get("SQ_INSTS_VALU_per_launch")
-                valu_busy = pj.get("valu_busy_frac_pmc")
-                pmc_src = pj.get("source")
-        except (OSError, KeyError, ValueError):
-            pass
+        pj = committed_pmc(P, K, W, D, world, args.dtype) if (dist is None and args.ensemble == "truth" and args.width_scale == 1.0) else None
+        if pj is not None:
+            traffic = (2.0 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024.0
+            valu_instr = pj.get("SQ_INSTS_VALU_per_launch")
+            valu_busy = pj.get("valu_busy_frac_pmc")
+            pmc_src = pj.get("source")
+        valu_peak = VALU_PEAK_LANE_INSTR if args.dtype == "f64" else VALU_PEAK_LANE_INSTR_F32
         achieved = per_launch_units * b_alg / (avg_ms * 1e-3) / 1e9 if k_n else None
         flop_ws = P * (K * F_W_FLOPS + F_PX_FLOPS)
         line = {
@@ -554,19 +574,23 @@ def main():
                          "algorithmic_bytes_per_launch": per_launch_units * b_alg,
                          "kernel": "k_half_step", "avg_launch_ms": avg_ms, "launches": k_n,
                          "alg_bytes_per_walker_step": b_alg, "walker_steps_per_launch": per_launch_units,
-                         "binding_roof": "fp64 VALU issue",
+                         "binding_roof": "%s VALU issue" % ("fp64" if args.dtype == "f64" else "fp32"),
                          "valu": None if not (valu_instr and k_n) else {
-                             "peak_lane_instr_per_s": VALU_PEAK_LANE_INSTR,
+                             "peak_lane_instr_per_s": valu_peak,
                              "executed_lane_instr_per_s": valu_instr * 64 / (avg_ms * 1e-3),
-                             "valu_issue_frac": valu_instr * 64 / (avg_ms * 1e-3) / VALU_PEAK_LANE_INSTR,
-                             "valu_busy_frac_pmc": valu_busy,
+                             "valu_issue_frac": valu_instr * 64 / (avg_ms * 1e-3) / valu_peak,
+                             "valu_issue_frac_is": "against the %s roof (%d lanes per clock and SIMD)%s" % (
+                                 args.dtype, 16 if args.dtype == "f64" else 32,
+                                 "" if args.dtype == "f64" else "; the kernel's fp64 and integer instructions (staging, table build, "
+                                 "classification, the far-field transform, chi^2 accumulation) issue at half that rate, so 1.0 is not reachable"),
+                             "valu_busy_frac_pmc": valu_busy if args.dtype == "f64" else None,
                              "valu_busy_is": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), both from the "
                                              "committed PMC passes: the share of SIMD cycles with a VALU instruction in flight "
                                              "(a little above the issue fraction: reciprocals and integer multiplies take more "
                                              "than one 4-cycle pass)",
                              "formula": "SQ_INSTS_VALU (wave instructions per launch, committed PMC pass) x 64 lanes / launch time "
-                                        "/ (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz)"},
-                         "flops": {"F_w": F_W_FLOPS, "F_px": F_PX_FLOPS, "flop_per_walker_step": flop_ws,
+                                        "/ (256 CUs x 4 SIMDs x %d lanes/clk x 2.4 GHz)" % (16 if args.dtype == "f64" else 32)},
+                         "flops": None if args.dtype != "f64" else {"F_w": F_W_FLOPS, "F_px": F_PX_FLOPS, "flop_per_walker_step": flop_ws,
                                    "nominal_TFLOPs": value * flop_ws / 1e12 / world, "peak_TFLOPs": FP64_PEAK_TFLOPS,
                                    "frac_nominal": value * flop_ws / 1e12 / world / FP64_PEAK_TFLOPS,
                                    "note": "NOMINAL: P (K F_w + F_px) per walker-step as if every (pixel, line) pair were "

@@ -100,3 +100,68 @@ def test_generator_reproduces_committed_file(tmp_path):
     Mc, nc = _load()
     got = np.array([[float(M[i, j]) for j in range(N)] for i in range(ROWS)])
     assert np.array_equal(got, Mc) and np.array_equal(np.array([float(v) for v in nodes]), nc)
+
+
+# ---- fp32 contexts: the 8-node transform (vamp_amd/csrc/ff_matrix32.inc) ----------------------------
+INC32 = os.path.join(ROOT, "vamp_amd", "csrc", "ff_matrix32.inc")
+N32, DEG32, ROWS32 = 8, 7, 32
+
+
+def _load32():
+    txt = open(INC32).read()
+    assert f"FF32_DEG = {DEG32}" in txt and f"FF32_ROWS = {ROWS32}" in txt and f"FF32_NODES = {N32}" in txt
+    body = txt[txt.index("{") + 1:txt.rindex("}")]
+    vals = np.array([np.float32(v) for v in re.findall(r"([-+]?\d\.\d+e[-+]\d+)f", body)], dtype=np.float32)
+    assert vals.size == ROWS32 * N32 + N32
+    m = vals[:ROWS32 * N32].reshape(N32 // 4, ROWS32, 4)            # [n/4][lane][n%4]
+    M = np.empty((ROWS32, N32), dtype=np.float32)
+    for n4 in range(N32 // 4):
+        M[:, 4 * n4:4 * n4 + 4] = m[n4]
+    return M, vals[ROWS32 * N32:]
+
+
+def _series_eval32(a, tt):
+    """the fp32 kernel's evaluation, in float32 arithmetic: quarter by pixel index, Horner in u = 4 (t - t0)"""
+    out = np.empty(tt.size, dtype=np.float32)
+    for i, t in enumerate(tt.astype(np.float32)):
+        q = i // 64
+        u = np.float32((t - np.float32(-0.75 + 0.5 * q)) * np.float32(4.0))
+        acc = a[q * (DEG32 + 1) + DEG32]
+        for j in range(DEG32 - 1, -1, -1):
+            acc = np.float32(acc * u + a[q * (DEG32 + 1) + j])
+        out[i] = acc
+    return out
+
+
+def test_f32_matrix_nodes_conditioning_and_constants():
+    M, nodes = _load32()
+    assert np.allclose(nodes, np.cos(np.pi * (np.arange(N32) + 0.5) / N32), rtol=0, atol=1e-7)
+    assert np.abs(M.astype(np.float64)).sum(axis=1).max() < 3.5          # (the 16-node matrix: 280) -- safe in fp32
+    s = M.astype(np.float64).sum(axis=1).reshape(4, DEG32 + 1)
+    assert np.allclose(s[:, 0], 1.0, atol=3e-7) and np.abs(s[:, 1:]).max() < 1e-6
+
+
+@pytest.mark.parametrize("dist,yy", [(4.0, 1e-6), (4.0, 0.5), (6.0, 1e-3), (20.0, 1e-3), (200.0, 0.3)])
+def test_f32_far_line_profile_accuracy(dist, yy):
+    """the 8-node series in float32 arithmetic against the exact Lorentzian wing of a line `dist` half-widths
+    beyond the tile's edge: <= 1e-6 relative at the far-field criterion (dist = 4) -- interpolation 3e-7 plus
+    single-precision rounding -- against W4's own 1e-4"""
+    M, nodes = _load32()
+    c = 1.0 + dist
+    f = lambda t: 1.0 / ((t - c) ** 2 + yy ** 2)
+    tt = -1.0 + 2.0 * np.arange(256) / 255.0
+    a = (M @ f(nodes.astype(np.float64)).astype(np.float32)).astype(np.float32)
+    got = _series_eval32(a, tt)
+    assert (np.abs(got - f(tt)) / f(tt)).max() < 1e-6
+
+
+def test_generator_reproduces_committed_f32_file():
+    pytest.importorskip("mpmath")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import importlib
+    g = importlib.import_module("gen_ff_matrix")
+    M, nodes = g.build(N32, DEG32)
+    Mc, nc = _load32()
+    got = np.array([[np.float32(float("%.9e" % float(M[i, j]))) for j in range(N32)] for i in range(ROWS32)], dtype=np.float32)
+    assert np.array_equal(got, Mc)
+    assert np.array_equal(np.array([np.float32(float("%.9e" % float(v))) for v in nodes], dtype=np.float32), nc)

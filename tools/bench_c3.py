@@ -104,11 +104,36 @@ def main():
     b_alg = float(np.sum(a.walkers * (3 * P + 3 * D + 2) * s))          # per step, all regions
     evals = float(np.sum(a.walkers * P * K))
     acc = np.mean(acc_mine) / (a.steps + a.warmup)
+    # roofline object in the form of bench.py's (contract: algorithmic bytes against the HBM peak; the binding roof is
+    # VALU issue, quoted from the committed PMC passes of this command -- profiles/pmc_traffic_c3*.json)
+    from bench import committed_pmc, VALU_PEAK_LANE_INSTR, VALU_PEAK_LANE_INSTR_F32
+    half_ms = ms / max(1, n)                       # HIP events around ALL launches of a half-step (the classes run concurrently)
+    pj = committed_pmc(0, 0, a.walkers, 0, world, a.dtype, workload="q1422") if world == 1 and a.packing == 0 else None
+    valu_peak = VALU_PEAK_LANE_INSTR if a.dtype == "f64" else VALU_PEAK_LANE_INSTR_F32
+    roof = {"bound": "hbm", "achieved": b_alg / 2 / (half_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+            "frac": b_alg / 2 / (half_ms * 1e-3) / 8e12,
+            "achieved_is": "algorithmic GB/s: sum over regions of W (3 P + 3 D + 2) s bytes per step (SURVEY 8d), half of it per half-step, "
+                           "/ the HIP-event time of a half-step (all launch classes)",
+            "traffic": None if pj is None else (2.0 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024.0,
+            "traffic_is": "HBM bytes per half-step, (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB summed over the half-step's kernels, from the committed PMC passes",
+            "traffic_source": None if pj is None else pj["source"],
+            "kernel": "k_half_step (one launch per launch class) + k_draws", "avg_half_step_ms": half_ms, "half_steps": n,
+            "algorithmic_bytes_per_half_step": b_alg / 2,
+            "binding_roof": "%s VALU issue" % ("fp64" if a.dtype == "f64" else "fp32"),
+            "valu": None if pj is None else {
+                "peak_lane_instr_per_s": valu_peak,
+                "executed_lane_instr_per_s": pj["SQ_INSTS_VALU_per_launch"] * 64 / (half_ms * 1e-3),
+                "valu_issue_frac": pj["SQ_INSTS_VALU_per_launch"] * 64 / (half_ms * 1e-3) / valu_peak,
+                "valu_busy_frac_pmc": pj.get("valu_busy_frac_pmc"),
+                "formula": "sum over the half-step's kernels of SQ_INSTS_VALU (wave instructions, committed PMC pass) x 64 lanes / "
+                           "half-step time / (256 CUs x 4 SIMDs x %d lanes/clk x 2.4 GHz)" % (16 if a.dtype == "f64" else 32)}}
     print(json.dumps({"config": "q1422: %d regions, sum P = %d, sum K = %d, W = %d per region, %s" % (R, P.sum(), K.sum(), a.walkers, a.dtype),
+                      "metric": "region-walker-steps/sec", "dtype": a.dtype,
                       "n_gpus": world, "regions_on_rank0": len(batch.mine),
                       "region_walker_steps_per_s": R * a.walkers * a.steps / dt, "ms_per_step": dt / a.steps * 1e3,
                       "avg_launch_ms": ms / max(1, n), "faddeeva_gevals_per_s": evals * a.steps / dt / 1e9,
                       "algorithmic_GBps": b_alg * a.steps / dt / 1e9, "hbm_frac": b_alg * a.steps / dt / 8e12 / world,
+                      "roofline": roof,
                       "acceptance_fraction": float(acc), "packing": a.packing}))
 
 

@@ -204,6 +204,7 @@ constexpr int FF_NODES = 16;          // Chebyshev nodes of the far-field interp
 #endif
 constexpr double FF_DIST = VAMP_FF_DIST;   // a line is "far" from a tile when it lies >= FF_DIST half-widths beyond its edge
 #include "ff_matrix.inc"               // FF_M, FF_DEG, FF_ROWS, FF_MAT (tools/gen_ff_matrix.py)
+#include "ff_matrix32.inc"             // FF32_M, FF32_NODES, FF32_DEG, FF32_ROWS, FF32_MAT: the fp32 contexts' 8-node form
 
 template <int KCAP, bool OWN_DTAB = true>
 struct WalkerLds {
@@ -633,9 +634,19 @@ constexpr int FF_EXP = FF_MAT + FF_NODES;     // constants of the exp kernel (va
 constexpr int FF_TABLE = FF_EXP + vamp::EXP_TAB_N;   // the matrix [n/2][lane][n%2], the node abscissae, the exp constants
 __device__ const double EXP_TAB[vamp::EXP_TAB_N] = VAMP_EXP_TAB_INIT;
 
+// fp32 contexts: the 32 x 8 matrix of the 8-node interpolant and its node abscissae, as floats (1 KB instead of 7.4)
+constexpr int FF32_TABLE = FF32_MAT + FF32_NODES;
+template <bool F32>
+constexpr int ff_table_doubles() { return F32 ? (FF32_TABLE + 1) / 2 : FF_TABLE; }
 // every thread of the workgroup copies its share; call before any thread can leave the kernel
+template <bool F32>
 __device__ __forceinline__ void ff_fill_table(double* dct) {
-    for (int e = threadIdx.x; e < FF_TABLE; e += blockDim.x) dct[e] = e < FF_EXP ? FF_M[e] : EXP_TAB[e - FF_EXP];
+    if constexpr (F32) {
+        float* d32 = reinterpret_cast<float*>(dct);
+        for (int e = threadIdx.x; e < FF32_TABLE; e += blockDim.x) d32[e] = FF32_M[e];
+    } else {
+        for (int e = threadIdx.x; e < FF_TABLE; e += blockDim.x) dct[e] = e < FF_EXP ? FF_M[e] : EXP_TAB[e - FF_EXP];
+    }
     __syncthreads();
 }
 
@@ -719,9 +730,8 @@ __device__ __forceinline__ void ff_series(TileScratch& Sx, const double* __restr
     __builtin_amdgcn_wave_barrier();
 }
 // (b) optical depth of the far lines at the tile's Chebyshev nodes -> the tile's local power series in Sx.coef
-//     W4NODES (fp32 contexts): node values through Humlicek's W4 in fp32 -- every far point has
-//     |x| + y >= 8, so region II (or I, wave-uniform) applies; transform and coefficients stay fp64
-template <class LDS, bool W4NODES = false>
+//     (fp32 contexts: ff32_coefficients below, 8 nodes)
+template <class LDS>
 __device__ __forceinline__ void ff_coefficients(const LDS& L, TileScratch& Sx, const double* __restrict__ dct,
                                                 int lane, int nfar, double mid, double half) {
     const int node = lane & (FF_NODES - 1), grp = lane >> 4;
@@ -729,32 +739,6 @@ __device__ __forceinline__ void ff_coefficients(const LDS& L, TileScratch& Sx, c
     __builtin_amdgcn_wave_barrier();
     // 1. lane = (slot group, node), four lines per lane (line q = 4 t + group of the compacted far list)
     const double xnode = fma(half, tnode, mid);
-    if constexpr (W4NODES) {
-        const float xn = (float)xnode;
-        float X[4], yv[4], av[4], lo;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int q = 4 * t + grp;
-            const float* lf = reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.linef) + Sx.farlist[q < nfar ? q : nfar - 1]);
-            X[t] = fabsf(xn - lf[0]) * lf[1];
-            yv[t] = lf[2];
-            av[t] = q < nfar ? lf[3] : 0.0f;
-            lo = t ? fminf(lo, X[t] + yv[t]) : X[0] + yv[0];
-        }
-        float fsf = 0.0f;
-        if (!__any(!(lo >= 15.0f))) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fsf = fmaf(av[t], vamp::w4_region1(X[t], yv[t]), fsf);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fsf = fmaf(av[t], vamp::w4_region2(X[t], yv[t]), fsf);
-        }
-        double fs = (double)fsf;
-        fs += __shfl_xor(fs, 16, 64);
-        fs += __shfl_xor(fs, 32, 64);
-        ff_series<float>(Sx, dct, lane, fs);
-        return;
-    }
     double Xn[4], yn[4], an[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1027,6 +1011,81 @@ __device__ __forceinline__ void sweep_range_f32(const RegionDev& R, const typena
     }
 }
 
+// ---- far field of fp32 contexts: 8 nodes ------------------------------------------------------------
+// Single precision holds 6e-8; an 8-node (degree-7) Chebyshev interpolant already reproduces the optical depth of
+// a line >= FF_DIST half-widths beyond the tile's edge to 3e-7 (tests/test_ff_matrix.py), so the fp32 path uses
+// that instead of the 16-node one: lane = 8 (line slot) + node, two lines per lane, node sums over three xor
+// shuffles, a 32 x 8 float matrix (row sums <= 3.4: no conditioning problem in fp32) -> four local series of 8
+// coefficients, 7 multiply-adds per pixel.  Node values through W4 regions I / II (every far point has |z| >= 8).
+template <class LDS>
+__device__ __forceinline__ void ff32_coefficients(const LDS& L, TileScratch& Sx, const float* __restrict__ dct32, int lane, int nfar,
+                                                  double mid, double half) {
+    const int node = lane & (FF32_NODES - 1), grp = lane >> 3;
+    const float tnode = dct32[FF32_MAT + node];                    // cos(pi (node + 1/2) / 8)
+    __builtin_amdgcn_wave_barrier();
+    const float xn = (float)fma(half, (double)tnode, mid);
+    float X[2], yv[2], av[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int q = 8 * t + grp;
+        const float* lf = reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.linef) + Sx.farlist[q < nfar ? q : nfar - 1]);
+        X[t] = fabsf(xn - lf[0]) * lf[1];
+        yv[t] = lf[2];
+        av[t] = q < nfar ? lf[3] : 0.0f;
+    }
+    float fs;
+    if (nfar > 8) {
+        const float lo = fminf(X[0] + yv[0], X[1] + yv[1]);
+        if (!__any(!(lo >= 15.0f))) fs = fmaf(av[0], vamp::w4_region1(X[0], yv[0]), av[1] * vamp::w4_region1(X[1], yv[1]));
+        else fs = fmaf(av[0], vamp::w4_region2(X[0], yv[0]), av[1] * vamp::w4_region2(X[1], yv[1]));
+    } else {
+        if (!__any(!(X[0] + yv[0] >= 15.0f))) fs = av[0] * vamp::w4_region1(X[0], yv[0]);
+        else fs = av[0] * vamp::w4_region2(X[0], yv[0]);
+    }
+    fs += __shfl_xor(fs, 8, 64);
+    fs += __shfl_xor(fs, 16, 64);
+    fs += __shfl_xor(fs, 32, 64);
+    // node sums (lanes 0..7 hold them) -> the four local series: lane l = 8 q + j < 32 owns coefficient j of quarter q
+    float* cf = reinterpret_cast<float*>(Sx.coef);
+    if (lane < FF32_NODES) cf[lane] = fs;
+    __builtin_amdgcn_wave_barrier();
+    const float4* mrow = reinterpret_cast<const float4*>(dct32) + (lane < FF32_ROWS ? lane : FF32_ROWS - 1);
+    const float4* fv = reinterpret_cast<const float4*>(Sx.coef);
+    const float4 m0 = mrow[0], m1 = mrow[FF32_ROWS], f0 = fv[0], f1 = fv[1];
+    float a0 = m0.x * f0.x, a1 = m0.y * f0.y;
+    a0 = fmaf(m0.z, f0.z, a0); a1 = fmaf(m0.w, f0.w, a1);
+    a0 = fmaf(m1.x, f1.x, a0); a1 = fmaf(m1.y, f1.y, a1);
+    a0 = fmaf(m1.z, f1.z, a0); a1 = fmaf(m1.w, f1.w, a1);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < FF32_ROWS) cf[lane] = a0 + a1;
+    __builtin_amdgcn_wave_barrier();
+}
+// Horner's rule at the tile's pixels (register t of a lane = pixel 64 t + lane: quarter t of an ascending grid)
+template <int T>
+__device__ __forceinline__ void ff32_horner(const TileScratch& Sx, const float (&xi)[T], double mid, double half, bool up,
+                                            float (&tau)[T]) {
+    static_assert(T == 4, "one pixel per quarter of the tile");
+    const float hf = (float)half, mf = (float)mid;
+    const float scale = 4.0f * __builtin_amdgcn_rcpf(hf);
+    float u[T], acc[T];
+    const float* cq[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int q = up ? t : T - 1 - t;
+        cq[t] = reinterpret_cast<const float*>(Sx.coef) + q * (FF32_DEG + 1);
+        u[t] = (xi[t] - fmaf(hf, 0.5f * q - 0.75f, mf)) * scale;
+        acc[t] = cq[t][FF32_DEG];
+    }
+#pragma unroll
+    for (int j = FF32_DEG - 1; j >= 0; --j) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = fmaf(acc[t], u[t], cq[t][j]);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) tau[t] += acc[t];
+    __builtin_amdgcn_wave_barrier();
+}
+
 // fp32 sweep of full tiles with the far field: near lines through W4 in fp32, all far lines through
 // the tile's interpolant -- node values and cosine transform in fp64 (one evaluation per lane,
 // same code as the fp64 path), transform in fp64, Horner per pixel in fp32.
@@ -1069,10 +1128,10 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const typ
 #endif
         if (nfar > 0) {
 #ifndef VAMP_SKIP_FFNODES
-            ff_coefficients<typename PK::Lds, true>(L, Sx, dct, lane, nfar, mid, half);
+            ff32_coefficients<typename PK::Lds>(L, Sx, reinterpret_cast<const float*>(dct), lane, nfar, mid, half);
 #endif
 #ifndef VAMP_SKIP_CLENSHAW
-            ff_horner<float, T>(Sx, xi, mid, half, x_hi > x_lo, tau);
+            ff32_horner<T>(Sx, xi, mid, half, x_hi > x_lo, tau);
 #endif
         }
 #pragma unroll
@@ -1320,10 +1379,10 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_lnprob(
     if (all) region = region_list ? region_list[blockIdx.y] : (int)blockIdx.y;
     __shared__ typename PK::Lds lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
     __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
-    __shared__ alignas(16) double dct[PK::FF ? FF_TABLE : 1];
+    __shared__ alignas(16) double dct[PK::FF ? ff_table_doubles<F32>() : 1];
     __shared__ double red[PARTS];
     __shared__ LineTables<table_doubles<F32, MODE, PK>()> tabs[PK::SPLIT ? 1 : PK::WPB];
-    if constexpr (PK::FF) ff_fill_table(dct);
+    if constexpr (PK::FF) ff_fill_table<F32>(dct);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
     const long long w = PK::SPLIT ? (long long)blockIdx.x : ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS + sub;
@@ -1551,10 +1610,10 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_st
     constexpr bool EXT = DRAWS == DRAW_HOST;
     __shared__ typename PK::Lds lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
     __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
-    __shared__ alignas(16) double dct[PK::FF ? FF_TABLE : 1];
+    __shared__ alignas(16) double dct[PK::FF ? ff_table_doubles<F32>() : 1];
     __shared__ double red[PARTS];
     __shared__ LineTables<table_doubles<F32, MODE, PK>()> tabs[PK::SPLIT ? 1 : PK::WPB];
-    if constexpr (PK::FF) ff_fill_table(dct);
+    if constexpr (PK::FF) ff_fill_table<F32>(dct);
     const int lane = threadIdx.x & 63;
     // the wave index is the same in every lane: say so, and the draws below (Philox rounds, the
     // split bijection -- all integer) run on the scalar unit when a wave serves one walker
