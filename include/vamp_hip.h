@@ -48,7 +48,7 @@ enum vamp_mode {
 enum vamp_dtype { VAMP_F64 = 0, VAMP_F32 = 1 };          /* per-pixel arithmetic type */
 enum vamp_wofz { VAMP_WOFZ_ACCURATE = 0, VAMP_WOFZ_HUMLICEK_W4 = 1 };
 
-#define VAMP_MAX_COMPONENTS 16
+#define VAMP_MAX_COMPONENTS 32
 #define VAMP_ABI_VERSION 3
 #define VAMP_COMM_ID_BYTES 128   /* = NCCL_UNIQUE_ID_BYTES */
 
@@ -79,13 +79,18 @@ int vamp_ctx_synchronize(vamp_ctx* ctx);
  *   65   64 lanes + the walker's own Taylor tables (four lines' at a time), <= 8 components, no far
  *        field (the blended regions of real spectra: a few lines over a few hundred pixels; regions
  *        of more than 512 pixels fall back to per-pixel evaluation without tables);
+ *   Regions of 17 .. VAMP_MAX_COMPONENTS components always run one walker per wavefront with every line
+ *   evaluated per pixel (no far-field interpolant, no Taylor tables: those shapes hold 16 lines) -- the
+ *   reference plans for such regions (vpspectrum.py:287-294: more than max_single_region_components = 15
+ *   lines means fewer attempts and a laxer chi^2 limit, not a refusal), so they work; they are not fast.
  *   0    choose: contexts that look like a real spectrum (<= 8 components everywhere, mean region
  *        <= 128 pixels) are split into launch classes -- regions with >= 3 components over 96..512
  *        pixels run as 65, the rest as 16 (64 in launches of fewer than 16 384 walkers); otherwise
  *        256 when every region has >= 2048 pixels, else 64.
  * The choice never depends on how an ensemble is sharded, so a shard runs the arithmetic of the
- * whole ensemble.  Takes effect at the next vamp_set_regions.  All shapes agree to rounding (fp32:
- * 64 and 256 bit for bit). */
+ * whole ensemble.  Takes effect at the next vamp_set_regions.  fp64: all shapes agree to rounding.
+ * fp32: 256 evaluates the line cores through single-precision Taylor rows instead of Humlicek's
+ * regions III / IV, so it agrees with the other shapes to W4's own error (~1e-4 relative in H). */
 int vamp_ctx_set_packing(vamp_ctx* ctx, int lanes_per_walker);
 
 /* Upload the data of n_regions independent absorption regions (replaces

@@ -399,7 +399,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
     for (int r = 0; r < n_regions; ++r) {
         const long long P = pix_off[r + 1] - pix_off[r];
         if (P < 2 || P > 0x7fffffff) return fail(VAMP_ERR_ARG, "vamp_set_regions: a region needs >= 2 pixels");
-        if (n_comp[r] < 1 || n_comp[r] > KMAX) return fail(VAMP_ERR_ARG, "vamp_set_regions: n_comp out of range (1..16)");
+        if (n_comp[r] < 1 || n_comp[r] > KMAX) return fail(VAMP_ERR_ARG, "vamp_set_regions: n_comp out of range (1..32)");
         Region d;
         d.pix_off = pix_off[r];
         d.P = (int)P; d.K = n_comp[r]; d.mode = mode; d.q = q; d.sample_sd = sample_sd ? 1 : 0;

@@ -55,7 +55,8 @@ def test_host_library_exports_the_whole_header(cpu_lib):
                                 gp.test_multi_region_batch_matches_single, gp.test_model_all_equals_model_region_by_region,
                                 gp.test_stretch_injected_draws_parity, gp.test_smallest_shapes,
                                 gp.test_sampler_resume_and_thin, gp.test_sampler_multi_region_matches_oracle,
-                                gp.test_sampler_sd_mode_and_acceptance, gp.test_map_all_follows_scipy_fmin],
+                                gp.test_sampler_sd_mode_and_acceptance, gp.test_map_all_follows_scipy_fmin,
+                                gp.test_regions_of_more_than_16_lines],
                          ids=lambda f: f.__name__)
 def test_gpu_parity_test_through_the_host_abi(fn, cpu_ctx):
     fn(cpu_ctx)

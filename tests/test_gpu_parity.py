@@ -608,9 +608,11 @@ def test_rare_branches_in_long_regions(hip_ctx):
 @pytest.mark.parametrize("P", [4096, 3000, 200])
 def test_split_workgroup_matches_wave_per_walker(P):
     """One walker per wavefront (packing 64) against one walker per 4-wavefront workgroup (packing
-    256: each wavefront sweeps every 4th tile).  Both sum chi^2 in the same order.  fp32: identical
-    bits and identical stretch-move trajectories.  fp64: the workgroup evaluates the line cores
-    through per-line Taylor tables (absolute error 2e-16 in H), so lnprob agrees to rounding."""
+    256: each wavefront sweeps every 4th tile).  Both sum chi^2 in the same order.  The workgroup shape
+    evaluates the line cores through per-line Taylor tables: in fp64 (absolute error 2e-16 in H) lnprob
+    agrees to rounding; in fp32 the tables replace Humlicek's regions III / IV (1e-4 relative, W4's own
+    error), so the two shapes agree to that -- |delta chi^2| / chi^2 <= 1e-3 is the fp32 tolerance of
+    SURVEY 8d, and both are checked against the fp64 workgroup run as well."""
     import vamp_amd
     from bench import make_workload
     wl = make_workload(P=P, K=5, W=64, seed=11, nbz=False)
@@ -626,13 +628,16 @@ def test_split_workgroup_matches_wave_per_walker(P):
             X, lp, nacc, _ = ctx.get_state()
             got.append((lnp, X, lp, nacc))
             ctx.close()
-        assert np.isfinite(got[0][0]).all() and got[0][3].sum() > 0
+        assert np.isfinite(got[0][0]).all() and got[0][3].sum() > 0 and got[1][3].sum() > 0
+        a, b = got[0][0], got[1][0]
         if dtype == vamp_amd.F32:
-            for a, b in zip(*got):
-                assert np.array_equal(a, b)
+            assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(a))) <= 1e-3
+            for v in (a, b):
+                assert np.max(np.abs(v - ref64) / np.maximum(1.0, np.abs(ref64))) <= 1e-3
+            assert np.max(np.abs(b - ref64) / np.maximum(1.0, np.abs(ref64))) <= 3e-5       # tables + W4 wings: well inside
         else:
-            a, b = got[0][0], got[1][0]
             assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(a))) <= 1e-12
+            ref64 = b
 
 
 def test_fp32_posterior_means_agree_with_fp64():
@@ -798,6 +803,49 @@ def test_full_size_dispersed_walkers_match_oracle(hip_ctx, grid):
     assert np.allclose(res["chain"], chain, rtol=1e-10, atol=1e-12), grid
     fin = np.isfinite(lchain[-1])
     assert np.allclose(res["lnprob"][-1][fin], lchain[-1][fin], rtol=1e-9, atol=1e-9), grid
+
+
+def test_regions_of_more_than_16_lines(hip_ctx):
+    """The reference sets no limit on the lines of a region (it plans for more than 15 and more than
+    22.5, vpspectrum.py:287-294); the fast launch shapes hold 16, regions of 17 .. 32 lines
+    (VAMP_MAX_COMPONENTS) take a plain shape in a launch class of their own.  One context with a
+    20-line, a 32-line and a 3-line region: log-posteriors and three stretch steps against the oracle,
+    with the free precision sd of the reference's likelihood on (D = 4 K + 1 = 129 for 32 lines)."""
+    if hip_ctx.packing_request in (16, 65):
+        pytest.skip("packings 16 and 65 hold 8 lines")
+    rng = np.random.default_rng(77)
+    xs, fs, ns, Ks, ths, regs = [], [], [], [], [], []
+    W = 280                                                     # >= 2 D + 2 for D = 129
+    for P, K in ((300, 20), (700, 32), (64, 3)):
+        x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+        th = np.empty((W, K, 4))
+        th[:, :, 0] = rng.uniform(0.05, 1.5, (W, K))
+        th[:, :, 1] = rng.uniform(x[0], x[-1], (W, K))
+        th[:, :, 2] = 10.0 ** rng.uniform(-3, 0.8, (W, K))
+        th[:, :, 3] = 10.0 ** rng.uniform(-0.3, 1.6, (W, K))
+        th = np.hstack([th.reshape(W, 4 * K), rng.uniform(0.01, 0.2, (W, 1))])
+        noise = np.ones(P)
+        flux = np.clip(1.0 + rng.normal(0, 0.05, P), 0, None)
+        xs.append(x); fs.append(flux); ns.append(noise); Ks.append(K); ths.append(th)
+        regs.append(vo.Region(x=x, flux=flux, noise=noise, n_comp=K, mode=vo.MODE_VOIGT4, sample_sd=True))
+    hip_ctx.set_regions(xs, fs, ns, Ks, mode=vo.MODE_VOIGT4, sample_sd=True)
+    assert hip_ctx.ndims == [81, 129, 13]
+    want = [vo.log_prob_batch_fast(r, t) for r, t in zip(regs, ths)]
+    got = hip_ctx.lnprob_all(ths)
+    for r in range(3):
+        assert np.isfinite(want[r]).all()
+        assert np.max(np.abs(got[r] - want[r]) / np.maximum(1.0, np.abs(want[r]))) <= 1e-9, r
+        assert np.array_equal(hip_ctx.lnprob(ths[r], region=r), got[r])
+    hip_ctx.sampler_init(ths, seed=3, split_block=W)
+    res = hip_ctx.run(3)
+    for r in range(3):
+        fn = lambda q, r=r: vo.log_prob_batch_fast(regs[r], q)
+        chain, _, nacc = vo.run_sampler(fn, ths[r], want[r], 3, seed=3, block=W, region=r, walker_off=r * W)
+        assert np.array_equal(res["n_accept"][r], nacc), r
+        assert np.allclose(res["chain"][r], chain, rtol=1e-10, atol=1e-12), r
+    tau, flux = hip_ctx.model(ths[1][0], region=1)
+    assert np.allclose(tau, np.array(list(vo.component_taus(regs[1], ths[1][0]))), rtol=1e-12, atol=1e-300)
+    assert np.allclose(flux, vo.model_flux(regs[1], ths[1][0]), rtol=1e-12)
 
 
 def test_descending_grid_long_region(hip_ctx):

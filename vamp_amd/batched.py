@@ -22,7 +22,7 @@ import numpy as np
 from . import hip_backend as hb
 from .vpfits import VPfit, _EnsembleMCMC, _MAP
 
-MAX_COMPONENTS = 16      # VAMP_MAX_COMPONENTS of include/vamp_hip.h
+MAX_COMPONENTS = 32      # VAMP_MAX_COMPONENTS of include/vamp_hip.h (the reference sets no limit, vpspectrum.py:287-294)
 
 
 class _DeferredModel:

@@ -68,10 +68,12 @@
 #endif
 namespace {
 
-constexpr int KMAX = VAMP_MAX_COMPONENTS;
+constexpr int KMAX = 16;                       // lines per region of the fast shapes (far field, Taylor tables, packing)
+constexpr int KMAX_ALL = VAMP_MAX_COMPONENTS;  // lines per region of the ABI: 17 .. 32 run the plain shape PackXL
+static_assert(KMAX_ALL >= KMAX && KMAX_ALL < 64, "lane k stages line k; one spare lane for sd");
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
-constexpr int DMAX = 4 * KMAX + 1;
+constexpr int DMAX = 4 * KMAX_ALL + 1;
 constexpr long long PACK_MIN_WALKERS = 16384;   // automatic packing: walkers per launch needed to pay off
 // automatic choice of a 4-wave workgroup per walker (shared Taylor tables of the line cores, see
 // LineTables): regions that give every wave >= 2 tiles.  The choice must not depend on the launch
@@ -197,6 +199,9 @@ using PackSmall2 = Pack<VAMP_SMALL2_LANES, 2, true, VAMP_SMALL2_WAVES>;
 #define VAMP_MID_PREDRAW 1
 #endif
 using PackMid = Pack<64, 8, true, VAMP_MID_WAVES, true, true, false>;
+// regions of 17 .. 32 lines (the reference sets no limit, vpspectrum.py:287-294): one walker per wavefront, every
+// line evaluated per pixel, no far field and no tables; 15 KB of LDS per walker, two walkers per workgroup
+using PackXL = Pack<64, KMAX_ALL, true, 2, false, false, false>;
 
 constexpr int FF_NODES = 16;          // Chebyshev nodes of the far-field interpolant of one tile
 #ifndef VAMP_FF_DIST
@@ -258,7 +263,7 @@ __device__ __forceinline__ void group_barrier() {
     if constexpr (PK::SPLIT) __syncthreads();
     else __builtin_amdgcn_wave_barrier();
 }
-using WaveLds = WalkerLds<KMAX, true>;      // the one-walker-per-wavefront kernels (k_model, k_line_records)
+using WaveLds = WalkerLds<KMAX_ALL, true>;  // the one-walker-per-wavefront kernels (k_model, k_line_records): = PackXL::Lds
 
 // ---------------------------------------------------------------------------------------
 // wave helpers
@@ -1428,7 +1433,7 @@ __global__ __launch_bounds__(BLOCK) void k_model(const RegionDev* __restrict__ r
     WaveLds& L = lds[wave];
     for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[d];
     __builtin_amdgcn_wave_barrier();
-    (void)stage_lines<MODE>(R, L, lane, false, 0);
+    (void)stage_lines<MODE, PackXL>(R, L, lane, false, 0);
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= R.P) return;
     const double xi = px.x[R.pix_off + i];
@@ -1459,7 +1464,7 @@ __global__ __launch_bounds__(64) void k_line_records(const RegionDev* __restrict
     WaveLds& L = lds[0];
     for (int d = lane; d < R.D; d += 64) L.theta[d] = theta[d];
     __builtin_amdgcn_wave_barrier();
-    const double lp = stage_lines<MODE>(R, L, lane, false, 0);
+    const double lp = stage_lines<MODE, PackXL>(R, L, lane, false, 0);
     if (lane < R.K) {
         rec[5 * lane + 0] = L.line[lane].c;
         rec[5 * lane + 1] = L.line[lane].s;
@@ -1748,12 +1753,13 @@ struct DevBuf {
     } while (0)
 #define VAMP_FOR_MODE(mode, ...) VAMP_FOR_MODE_(mode, __VA_ARGS__)
 // launch shapes (see struct Pack): what one launch class of a context runs
-enum Shape { SH_SMALL = 0, SH_MID = 1, SH_WIDE = 2, SH_WIDE_FULL = 3, SH_SPLIT = 4, SH_SPLIT_FULL = 5, SH_SMALL2 = 6 };
+enum Shape { SH_SMALL = 0, SH_MID = 1, SH_WIDE = 2, SH_WIDE_FULL = 3, SH_SPLIT = 4, SH_SPLIT_FULL = 5, SH_SMALL2 = 6, SH_XL = 7 };
 #define VAMP_FOR_MODE_PK(mode, shape, ...)                                              \
     do {                                                                        \
         if ((shape) == SH_SMALL) { using PK = PackSmall; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else if ((shape) == SH_SMALL2) { using PK = PackSmall2; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else if ((shape) == SH_MID) { using PK = PackMid; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
+        else if ((shape) == SH_XL) { using PK = PackXL; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else if ((shape) == SH_SPLIT_FULL) { using PK = PackSplitFull; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else if ((shape) == SH_SPLIT) { using PK = PackSplit; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
         else if ((shape) == SH_WIDE_FULL) { using PK = PackWideFull; VAMP_FOR_MODE_(mode, __VA_ARGS__); } \
@@ -1761,17 +1767,17 @@ enum Shape { SH_SMALL = 0, SH_MID = 1, SH_WIDE = 2, SH_WIDE_FULL = 3, SH_SPLIT =
     } while (0)
 inline long long shape_walkers_per_block(int sh) {
     return sh == SH_SMALL ? PackSmall::WALKERS_PER_BLOCK : sh == SH_SMALL2 ? PackSmall2::WALKERS_PER_BLOCK : sh == SH_MID ? PackMid::WALKERS_PER_BLOCK
-           : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? 1 : PackWide::WALKERS_PER_BLOCK;
+           : sh == SH_XL ? PackXL::WALKERS_PER_BLOCK : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? 1 : PackWide::WALKERS_PER_BLOCK;
 }
 inline unsigned shape_threads(int sh) {
     return sh == SH_SMALL ? PackSmall::THREADS : sh == SH_SMALL2 ? PackSmall2::THREADS : sh == SH_MID ? PackMid::THREADS
-           : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? PackSplit::THREADS : PackWide::THREADS;
+           : sh == SH_XL ? PackXL::THREADS : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? PackSplit::THREADS : PackWide::THREADS;
 }
 
 // A launch class: the regions of a context that one kernel shape serves.  Real spectra mix many
 // short single-line regions (four walkers per wavefront) with a few long blends (a wavefront per
 // walker with Taylor tables); each class is one launch per half-step over its own region list.
-enum ClassKind { CK_SMALL = 0, CK_MID = 1, CK_WIDE = 2, CK_SMALL2 = 3 };
+enum ClassKind { CK_SMALL = 0, CK_MID = 1, CK_WIDE = 2, CK_SMALL2 = 3, CK_XL = 4 };
 struct LaunchClass {
     int kind = CK_WIDE;
     std::vector<int> regions;
@@ -1945,6 +1951,7 @@ int ensure_part_events(vamp_ctx* c, int parts) {
 // of it), so that a shard runs the shape -- the same bits -- the whole ensemble runs on one device; the
 // packed shapes (several walkers per wavefront) only pay off for ensembles that fill the chip.
 int class_shape(const vamp_ctx* c, const LaunchClass& cl, long long n_walkers, bool packable) {
+    if (cl.kind == CK_XL) return SH_XL;
     if (cl.kind == CK_MID) return SH_MID;
     if ((cl.kind == CK_SMALL || cl.kind == CK_SMALL2) && packable && (c->packing == 16 || n_walkers >= PACK_MIN_WALKERS))
         return cl.kind == CK_SMALL2 ? SH_SMALL2 : SH_SMALL;
@@ -2436,7 +2443,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
     for (int r = 0; r < n_regions; ++r) {
         const long long P = pix_off[r + 1] - pix_off[r];
         if (P < 2 || P > 0x7fffffff) return fail(VAMP_ERR_ARG, "vamp_set_regions: a region needs >= 2 pixels");
-        if (n_comp[r] < 1 || n_comp[r] > KMAX) return fail(VAMP_ERR_ARG, "vamp_set_regions: n_comp out of range (1..16)");
+        if (n_comp[r] < 1 || n_comp[r] > KMAX_ALL) return fail(VAMP_ERR_ARG, "vamp_set_regions: n_comp out of range (1..32)");
         RegionDev d;
         std::memset(&d, 0, sizeof(d));
         d.pix_off = pix_off[r];
@@ -2516,35 +2523,46 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
     HIP_TRY(hipMalloc(&c->regions_d, n_regions * sizeof(RegionDev)));
     HIP_TRY(hipMemcpy(c->regions_d, R.data(), n_regions * sizeof(RegionDev), hipMemcpyHostToDevice));
     {
-        int kmax = 0;
-        for (int r = 0; r < n_regions; ++r) kmax = std::max(kmax, R[r].K);
-        const double mean_p = (double)pix_off[n_regions] / n_regions;
-        if ((c->packing == 16 || c->packing == 65) && kmax > PackSmall::KCAP)
-            return fail(VAMP_ERR_ARG, "vamp_set_regions: packings 16 and 65 support at most 8 components per region");
+        // regions of more than KMAX lines form their own class (plain shape PackXL); everything below is about the others
+        int kmax = 0, n_std = 0;
+        long long pix_std = 0;
         c->full_tiles = true;
-        for (int r = 0; r < n_regions; ++r) c->full_tiles = c->full_tiles && (R[r].P % (64 * TPIX) == 0);
-        c->min_tiles = R[0].P / (64 * TPIX);
-        for (int r = 1; r < n_regions; ++r) c->min_tiles = std::min(c->min_tiles, R[r].P / (64 * TPIX));
+        c->min_tiles = 0x7fffffff;
+        for (int r = 0; r < n_regions; ++r) {
+            if (R[r].K > KMAX) continue;
+            kmax = std::max(kmax, R[r].K);
+            n_std += 1;
+            pix_std += R[r].P;
+            c->full_tiles = c->full_tiles && (R[r].P % (64 * TPIX) == 0);
+            c->min_tiles = std::min(c->min_tiles, R[r].P / (64 * TPIX));
+        }
+        if (n_std == 0) c->min_tiles = 0;
+        const double mean_p = n_std ? (double)pix_std / n_std : 0.0;
+        if ((c->packing == 16 || c->packing == 65) && (kmax > PackSmall::KCAP || n_std < n_regions))
+            return fail(VAMP_ERR_ARG, "vamp_set_regions: packings 16 and 65 support at most 8 components per region");
         // launch classes.  Forced packings: one class.  Automatic: contexts that look like a real
         // spectrum (<= 8 lines everywhere, mean region <= 128 px) split into the blends worth a
         // wavefront and a set of Taylor tables per walker (>= 3 lines over >= 96 px: table building
         // costs ~2 near-axis evaluations per line and interval, repaid from ~30 px per line on) and
         // the rest, four walkers to a wavefront; everything else is one wide class.
         c->class_of.assign(n_regions, 0);
-        const bool spectrum_like = c->packing == 0 && kmax <= PackSmall::KCAP && mean_p <= 128.0;
-        LaunchClass cls[3];
+        const bool spectrum_like = c->packing == 0 && n_std == n_regions && kmax <= PackSmall::KCAP && mean_p <= 128.0;
+        LaunchClass cls[4];
         cls[0].kind = c->packing == 16 ? CK_SMALL : c->packing == 65 ? CK_MID : spectrum_like ? CK_SMALL : CK_WIDE;
         cls[1].kind = CK_MID;
         cls[2].kind = CK_SMALL2;
+        cls[3].kind = CK_XL;
         for (int r = 0; r < n_regions; ++r) {
             int k = 0;
-            if (spectrum_like) {
+            if (R[r].K > KMAX) {
+                k = 3;
+            } else if (spectrum_like) {
                 if (R[r].K >= VAMP_MID_MIN_K && R[r].P >= VAMP_MID_MIN_P && R[r].P <= BLEND_MAX_PIXELS && mode != VAMP_GAUSS3 && !c->f32) k = 1;
                 else if (R[r].K <= PackSmall2::KCAP) k = 2;
             }
             cls[k].regions.push_back(r);
         }
-        for (int k : {1, 2, 0})          // blends first: the longest launch starts first when the classes overlap
+        for (int k : {1, 2, 0, 3})       // blends first: the longest launch starts first when the classes overlap
             if (!cls[k].regions.empty()) {
                 for (int r : cls[k].regions) c->class_of[r] = (int)c->classes.size();
                 c->classes.push_back(cls[k]);

@@ -15,7 +15,7 @@ from scipy.signal import argrelextrema
 
 from .vpfits import VPfit
 
-MAX_COMPONENTS = 16      # VAMP_MAX_COMPONENTS of include/vamp_hip.h
+MAX_COMPONENTS = 32      # VAMP_MAX_COMPONENTS of include/vamp_hip.h (the reference sets no limit, vpspectrum.py:287-294)
 
 
 class VPregion():
