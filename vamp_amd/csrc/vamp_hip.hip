@@ -238,10 +238,15 @@ constexpr bool use_tables() { return PK::TABS && !F32 && MODE != VAMP_GAUSS3; }
 template <bool F32, int MODE, class PK>
 constexpr bool use_tables32() { return VAMP_F32_TABLES && PK::DTAB_IN_TABLES && F32 && MODE != VAMP_GAUSS3; }
 constexpr int TAB32_DOUBLES = KMAX * vamp::TAB32_LINE / 2;       // the float rows, counted in doubles
+// fp32 contexts, blend shape (one wavefront per walker, <= 8 lines over <= 512 pixels): the fp32 rows of ALL its
+// lines resident (512 B per line), built from the walker's own near-axis tables
+template <bool F32, int MODE, class PK>
+constexpr bool use_blend32() { return VAMP_F32_TABLES && F32 && PK::LINES_PER_PASS > 0 && MODE != VAMP_GAUSS3; }
 template <bool F32, int MODE, class PK>
 constexpr int table_doubles() {
     return use_tables<F32, MODE, PK>() ? PK::TAB_LINES * vamp::TAB_LINE
-           : use_tables32<F32, MODE, PK>() ? TAB32_DOUBLES + KMAX * vamp::DTAB_N : 2;
+           : use_tables32<F32, MODE, PK>() ? TAB32_DOUBLES + KMAX * vamp::DTAB_N
+           : use_blend32<F32, MODE, PK>() ? PK::KCAP * vamp::TAB32_LINE / 2 : 2;
 }
 // wavefronts per SIMD the register allocation aims for: fp32 instructions issue in 2 cycles on a SIMD but one
 // wavefront can issue only every 4, so the fp32 form of the workgroup-per-walker shape wants MORE resident
@@ -290,7 +295,7 @@ __device__ __forceinline__ double uniform_logp(double v, double lo, double hi, d
 // Turn theta (in LDS) into line records + prior.  Returns log-prior on every lane.
 // MODE is a compile-time parameter: one specialised kernel per parameterisation, no mode
 // branches in the staging code or in the pixel loop.
-template <int MODE, class PK = PackWide, bool TAB = false, bool TAB32 = false>
+template <int MODE, class PK = PackWide, bool TAB = false, bool TAB32 = false, bool DT32 = false>
 __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::Lds& L, int lane, bool want_f32, int part,
                                               double* tab = nullptr) {
     // `lane` is the lane index inside the walker's group (0 .. LPW-1).  In a split workgroup
@@ -373,7 +378,7 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
 #ifdef VAMP_SKIP_DTAB     // timing-only builds (tools/variants.py)
     if (false) {
 #else
-    if (MODE != VAMP_GAUSS3 && (!want_f32 || TAB32)) {
+    if (MODE != VAMP_GAUSS3 && (!want_f32 || TAB32 || DT32)) {      // (DT32: an fp32 blend builds its rows from L.dtab)
 #endif
         constexpr int STEP = PK::SPLIT ? PK::THREADS : PK::LPW;
         for (int e = PK::SPLIT ? 64 * part + lane : lane; e < K * vamp::DTAB_N; e += STEP) {
@@ -1281,6 +1286,60 @@ __device__ __forceinline__ double sweep_blend_passes(const RegionDev& R, const t
     return wave_sum<64>(chi);
 }
 
+// fp32 blends: rows of every line built once (one (line, interval) pair per lane and round), then ONE sweep of the
+// region's <= 512 pixels, 1..4 per lane and chunk, lines innermost: W4 regions I / II in the wings, a table look-up
+// in the cores (tile_w4_tab)
+template <int MODE, class PK, int T>
+__device__ __forceinline__ void blend32_chunk(const RegionDev& R, const typename PK::Lds& L, const float* __restrict__ x,
+                                              const float* __restrict__ f, const float* __restrict__ wt, int lane, int base,
+                                              const float* tab32, double& chi) {
+    float xi[T], tau[T];
+    int idx[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int i = base + 64 * t + lane;
+        idx[t] = i < R.P ? i : R.P - 1;
+        xi[t] = x[idx[t]];
+        tau[t] = 0.0f;
+    }
+    for (int k = 0; k < R.K; ++k) {
+        const float c = L.linef[k][0], sc = L.linef[k][1], y = L.linef[k][2], a = L.linef[k][3];
+        float X[T], H[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) X[t] = fabsf(xi[t] - c) * sc;
+        tile_w4_tab<T>(y, X, H, tab32 + k * vamp::TAB32_LINE);
+#pragma unroll
+        for (int t = 0; t < T; ++t) tau[t] = fmaf(a, H[t], tau[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float m = __expf(-tau[t]);
+        const float r = (f[idx[t]] - m) * wt[idx[t]];
+        chi += (base + 64 * t + lane) < R.P ? (double)r * (double)r : 0.0;
+    }
+}
+template <int MODE, class PK>
+__device__ __forceinline__ double sweep_blend32(const RegionDev& R, const typename PK::Lds& L, const PixPtrs& px, int lane, float* tab32) {
+    static_assert(PK::WPB == 1 && PK::LPW == 64, "one wavefront per walker");
+    const float* __restrict__ x = px.xf + R.pix_off;
+    const float* __restrict__ f = px.ff + R.pix_off;
+    const float* __restrict__ wt = px.wtf + R.pix_off;
+    for (int e = lane; e < R.K * vamp::TAB_NI; e += 64) {
+        const int k = e / vamp::TAB_NI, i = e % vamp::TAB_NI;
+        vamp::taylor_table_row32(i, L.line[k].y, L.dtab[k], L.line[k].pole, L.line[k].hy, tab32 + k * vamp::TAB32_LINE + i * vamp::TAB32_NT);
+    }
+    __syncthreads();
+    double chi = 0.0;
+    for (int base = 0; base < R.P; base += 256) {
+        const int nt = (R.P - base + 63) >> 6;
+        if (nt >= 4) blend32_chunk<MODE, PK, 4>(R, L, x, f, wt, lane, base, tab32, chi);
+        else if (nt == 3) blend32_chunk<MODE, PK, 3>(R, L, x, f, wt, lane, base, tab32, chi);
+        else if (nt == 2) blend32_chunk<MODE, PK, 2>(R, L, x, f, wt, lane, base, tab32, chi);
+        else blend32_chunk<MODE, PK, 1>(R, L, x, f, wt, lane, base, tab32, chi);
+    }
+    return wave_sum<64>(chi);
+}
+
 template <bool F32, int MODE, class PK = PackWide>
 __device__ __forceinline__ double sweep_pixels(const RegionDev& R, const typename PK::Lds& L, TileScratch& Sx, const double* __restrict__ dct,
                                                const PixPtrs& px, int lane, int part, double* red, const double* tab) {
@@ -1290,6 +1349,11 @@ __device__ __forceinline__ double sweep_pixels(const RegionDev& R, const typenam
         double chi = 0.0;
         sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, 0, full, TILE, true, chi, tab);
         return wave_sum<PK::LPW>(chi);
+    } else if constexpr (use_blend32<F32, MODE, PK>()) {
+        if (R.P <= BLEND_MAX_PIXELS) return sweep_blend32<MODE, PK>(R, L, px, lane, reinterpret_cast<float*>(const_cast<double*>(tab)));
+        double chi = 0.0;      // (longer than a blend: only when this shape is forced on a long region)
+        sweep_class<F32, MODE, PK>(R, L, Sx, dct, px, lane, 0, full, TILE, true, chi, nullptr);
+        return wave_sum<64>(chi);
     } else if constexpr (PK::LINES_PER_PASS > 0 && use_tables<F32, MODE, PK>()) {
         if (R.P <= BLEND_MAX_PIXELS) return sweep_blend_passes<MODE, PK>(R, L, px, lane, const_cast<double*>(tab));
         // longer than the registers hold (only when this shape is forced on a long region): every
@@ -1352,8 +1416,8 @@ __device__ __forceinline__ double loglike_from_sum(const RegionDev& R, const LDS
 template <bool F32, int MODE, class PK = PackWide>
 __device__ __forceinline__ double wave_lnprob(const RegionDev& R, typename PK::Lds& L, TileScratch& Sx, const double* dct,
                                               const PixPtrs& px, int lane, double* chi_out, int part, double* red, double* tab) {
-    const double lp = stage_lines<MODE, PK, use_tables<F32, MODE, PK>() && PK::LINES_PER_PASS == 0, use_tables32<F32, MODE, PK>()>(
-        R, L, lane, F32, part, tab);
+    const double lp = stage_lines<MODE, PK, use_tables<F32, MODE, PK>() && PK::LINES_PER_PASS == 0, use_tables32<F32, MODE, PK>(),
+                                  use_blend32<F32, MODE, PK>()>(R, L, lane, F32, part, tab);
     if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
         if (chi_out) *chi_out = __builtin_nan("");
         return NEG_INF;
@@ -2557,7 +2621,8 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
             if (R[r].K > KMAX) {
                 k = 3;
             } else if (spectrum_like) {
-                if (R[r].K >= VAMP_MID_MIN_K && R[r].P >= VAMP_MID_MIN_P && R[r].P <= BLEND_MAX_PIXELS && mode != VAMP_GAUSS3 && !c->f32) k = 1;
+                if (R[r].K >= VAMP_MID_MIN_K && R[r].P >= VAMP_MID_MIN_P && R[r].P <= BLEND_MAX_PIXELS && mode != VAMP_GAUSS3 &&
+                    (!c->f32 || VAMP_F32_TABLES)) k = 1;
                 else if (R[r].K <= PackSmall2::KCAP) k = 2;
             }
             cls[k].regions.push_back(r);
