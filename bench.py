@@ -179,7 +179,11 @@ def cpu_reference_path(wl, budget_s=12.0):
                     "multiprocessing pool over walker chunks: the CPU path named by BASELINE.json",
             "sample": f"first {Wc} walkers of the same workload x 1 full step on {cores} processes (one per core of the "
                       f"affinity mask, {len(os.sched_getaffinity(0))} cores), {t:.1f} s; os.cpu_count() = {os.cpu_count()}",
-            "accepted": nacc}
+            "accepted": nacc,
+            "note": "BASELINE.md section 3 asks for all host cores, so this is one process per core of the affinity mask (SMT "
+                    "threads included).  On the 128-core / 256-thread hosts of these boxes one process per PHYSICAL core is "
+                    "faster (1 751-1 760 walker-steps/s with VAMP_CPU_WORKERS=128, round 2) than one per thread (1 485-1 523): "
+                    "wofz is bound by the FP units the two threads of a core share"}
 
 
 def cpu_c_port(wl, budget_s=10.0):

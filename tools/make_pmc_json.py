@@ -28,11 +28,13 @@ for ln in open(a.summary):
     parts = ln.split()
     if len(parts) >= 3 and parts[-1].startswith("mean=") and name:
         kernels[name][parts[0]] = (float(parts[-1][5:]), int(parts[-2]) if parts[-2].isdigit() else int(parts[-2].split("=")[-1]))
-n_ref = min(v["SQ_INSTS_VALU"][1] for k, v in kernels.items() if "k_half_step" in k)
+# launches per half-step of a kernel = its sample count of a counter / the sample count of the SAME counter for a
+# k_half_step kernel (the passes of different counter groups may see different numbers of launches)
+ref = next(v for k, v in sorted(kernels.items()) if "k_half_step" in k)
 tot = {}
 for k, v in kernels.items():
     for cname, (mean, n) in v.items():
-        tot[cname] = tot.get(cname, 0.0) + mean * n / n_ref
+        tot[cname] = tot.get(cname, 0.0) + mean * n / ref[cname][1]
 cfg = {"workload": a.workload, "walkers": a.walkers, "n_gpus": 1, "dtype": a.dtype}
 if a.workload == "headline":
     cfg.update(pixels=16384, components=16, ndim=48)
