@@ -805,6 +805,46 @@ def test_full_size_dispersed_walkers_match_oracle(hip_ctx, grid):
     assert np.allclose(res["lnprob"][-1][fin], lchain[-1][fin], rtol=1e-9, atol=1e-9), grid
 
 
+@pytest.mark.parametrize("packing", [0, 64])
+def test_full_size_dispersed_walkers_fp32(packing):
+    """The same non-converged walkers at the headline's full size through the fp32 path -- single-precision
+    Taylor rows in the line cores, W4 regions I / II in the wings, the 8-node far field (packing 0 = the
+    workgroup shape) and plain W4 everywhere (packing 64) -- against the fp64 oracle: SURVEY 8d's fp32
+    tolerance |delta chi^2| / chi^2 <= 1e-3, and the identical -inf pattern."""
+    import vamp_amd
+    rng = np.random.default_rng(31)
+    P, K, W = 16384, 16, 8
+    x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+    span = x[-1] - x[0]
+    th = np.empty((W, K, 4))
+    th[:, :, 0] = 10.0 ** rng.uniform(-2, 0.7, (W, K))
+    th[:, :, 1] = rng.uniform(x[0], x[-1], (W, K))
+    th[:, 0, 1] = np.where(rng.random(W) < 0.5, x[0], x[-1])
+    th[:, :, 2] = 10.0 ** rng.uniform(-6, np.log10(0.4 * span), (W, K))
+    th[:, :, 3] = 10.0 ** rng.uniform(-1.3, np.log10(0.4 * span), (W, K))
+    th[:, 1:4, 1] = np.clip(th[:, 1:2, 1] + rng.normal(0, 3.0, (W, 3)), x[0], x[-1])
+    th[:, 1:4, 3] = 10.0 ** rng.uniform(0.5, 1.5, (W, 3))
+    th[:, 4, 3] = 10.0 ** rng.uniform(-1.3, -0.7, W)
+    th[:4, 5:, 3] = 10.0 ** rng.uniform(1.0, 2.3, (4, K - 5))
+    th[:4, 5:, 2] = 10.0 ** rng.uniform(-1, 1.3, (4, K - 5))
+    th = th.reshape(W, 4 * K)
+    noise = np.full(P, 0.05)
+    flux = np.clip(1.0 + rng.normal(0, 0.05, P), 0, None)
+    r = vo.Region(x=x, flux=flux, noise=noise, n_comp=K, mode=vo.MODE_VOIGT4)
+    want, chi_w = vo.log_prob_batch_fast(r, th), None
+    with vamp_amd.HipContext(device=0, dtype=vamp_amd.F32) as ctx:
+        ctx.set_packing(packing)
+        ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
+        got, chi = ctx.lnprob(th, return_chi2=True)
+    assert np.array_equal(np.isfinite(want), np.isfinite(got))
+    fin = np.isfinite(want)
+    with vamp_amd.HipContext(device=0) as ctx:                    # chi^2 itself from the fp64 device path (== oracle to 1e-11)
+        ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
+        ref, chi_ref = ctx.lnprob(th, return_chi2=True)
+    assert np.max(np.abs(ref[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))) <= 1e-9
+    assert np.max(np.abs(chi[fin] - chi_ref[fin]) / chi_ref[fin]) <= 1e-3, packing
+
+
 def test_regions_of_more_than_16_lines(hip_ctx):
     """The reference sets no limit on the lines of a region (it plans for more than 15 and more than
     22.5, vpspectrum.py:287-294); the fast launch shapes hold 16, regions of 17 .. 32 lines

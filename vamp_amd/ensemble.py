@@ -21,8 +21,8 @@ the headline at world = 8.
                host logic run against an oracle-backed stand-in on CPU).
   "none"       single rank.
 
-Overlap: a rank's share can be cut into ``parts`` pieces; the exchange of piece p runs on the
-library's communication stream while the kernel of piece p + 1 computes.  Safe because a
+Overlap: a rank's share can be cut into ``parts`` pieces (default 1; ``VAMP_EXCHANGE_PARTS``); the
+exchange of piece p runs on the library's communication stream while the kernel of piece p + 1 computes.  Safe because a
 half-step kernel reads only rows of the frozen colour and writes only its own piece, while the
 scatter of piece p writes only rows of the moving colour of piece p.
 
@@ -138,7 +138,9 @@ class ShardedEnsemble:
             raise ValueError("W/split_block must be a multiple of the number of ranks")
         self.split_block = split_block
         if parts is None:
-            parts = int(os.environ.get("VAMP_EXCHANGE_PARTS", "0")) or (2 if self.exchange == "rccl" else 1)
+            # one piece until a multi-GPU run shows that the overlap pays: two 2048-walker pieces cost 8 % more kernel
+            # time than one 4096-walker launch at world 8 (profiles/r02_g_headline_shard_sizes.txt); bench.py times both
+            parts = int(os.environ.get("VAMP_EXCHANGE_PARTS", "0")) or 1
             while parts > 1 and (self.W // split_block) % (self.world * parts):
                 parts -= 1
         if parts < 1 or (self.W // split_block) % (self.world * parts):
