@@ -1912,6 +1912,10 @@ struct vamp_ctx {
     // grow-only scratch of vamp_lnprob (the MAP optimiser calls it thousands of times with W = 1)
     double *sc_th = nullptr, *sc_lp = nullptr, *sc_chi = nullptr;
     size_t sc_th_cap = 0, sc_w_cap = 0;
+    // small evaluations (the MAP searches: a few points per region, thousands of times): pinned host memory the
+    // kernel reads and writes directly -- no staging copies, one launch and one synchronisation per call
+    double *pin_th = nullptr, *pin_out = nullptr;
+    size_t pin_th_cap = 0, pin_out_cap = 0;
     // scratch for the ext hook
     int *ext_act_d = nullptr, *ext_par_d = nullptr;
     double *ext_z_d = nullptr, *ext_lu_d = nullptr;
@@ -2352,9 +2356,15 @@ int exchange_part(vamp_ctx* c, int part) {
         x1 = c->xev[c->xev_used].second;
         c->xev_used++;
     }
-    RCCL_TRY(api, api->AllGather(send, recv, count, RCCL_FLOAT64, c->comm, st));
-    rc = launch_scatter(c, part, st);
-    if (rc) return rc;
+    {
+        const int r_ = api->AllGather(send, recv, count, RCCL_FLOAT64, c->comm, st);
+        if (r_ == 0) rc = launch_scatter(c, part, st);
+        if (r_ != 0 || rc) {
+            if (x1) c->xev_used--;              // its closing event will never be recorded
+            if (r_ != 0) return fail(VAMP_ERR_COMM, std::string("ncclAllGather: ") + api->GetErrorString(r_));
+            return rc;
+        }
+    }
     if (x1) HIP_TRY(hipEventRecord(x1, st));
     if (overlap) HIP_TRY(hipEventRecord(c->ev_scatter[part], c->comm_stream));
     return 0;
@@ -2444,6 +2454,8 @@ int vamp_ctx_destroy(vamp_ctx* c) {
                     (void*)c->sc_lp, (void*)c->sc_chi, (void*)c->dr_ws, (void*)c->dr_wc, (void*)c->dr_z, (void*)c->dr_lu,
                     (void*)c->dr_lz})
         if (p) (void)hipFree(p);
+    if (c->pin_th) (void)hipHostFree(c->pin_th);
+    if (c->pin_out) (void)hipHostFree(c->pin_out);
     for (hipStream_t st : c->cls_stream) (void)hipStreamDestroy(st);
     for (hipEvent_t e : c->ev_join) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -2689,6 +2701,7 @@ int launch_lnprob(vamp_ctx* c, int region, long long W, const double* th_d, doub
     return 0;
 }
 
+constexpr size_t PINNED_EVAL_BYTES = 1u << 20;     // parameter blocks up to 1 MB are read by the kernel from pinned host memory
 // region >= 0: W parameter vectors of that region; region < 0: W vectors of EVERY region
 int lnprob_impl(vamp_ctx* c, int region, int64_t W, const double* theta, double* lnprob, double* chi2) {
     HIP_TRY(hipSetDevice(c->device));
@@ -2696,6 +2709,31 @@ int lnprob_impl(vamp_ctx* c, int region, int64_t W, const double* theta, double*
     const long long dsum = all ? c->regions_h.back().d_before + c->regions_h.back().D : c->regions_h[region].D;
     const size_t nth = (size_t)W * dsum;
     const size_t nout = (size_t)W * (all ? c->n_regions : 1);
+    if (nth * sizeof(double) <= PINNED_EVAL_BYTES) {
+        if (c->pin_th_cap < nth) {
+            if (c->pin_th) (void)hipHostFree(c->pin_th);
+            c->pin_th = nullptr; c->pin_th_cap = 0;
+            const size_t cap = std::max(nth, (size_t)4096);
+            HIP_TRY(hipHostMalloc(&c->pin_th, cap * sizeof(double), hipHostMallocDefault));
+            c->pin_th_cap = cap;
+        }
+        if (c->pin_out_cap < 2 * nout) {
+            if (c->pin_out) (void)hipHostFree(c->pin_out);
+            c->pin_out = nullptr; c->pin_out_cap = 0;
+            const size_t cap = std::max(2 * nout, (size_t)1024);
+            HIP_TRY(hipHostMalloc(&c->pin_out, cap * sizeof(double), hipHostMallocDefault));
+            c->pin_out_cap = cap;
+        }
+        std::memcpy(c->pin_th, theta, nth * sizeof(double));
+        double* lp_h = c->pin_out;
+        double* ch_h = chi2 ? c->pin_out + nout : nullptr;
+        int rc = launch_lnprob(c, region, W, c->pin_th, lp_h, ch_h);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::memcpy(lnprob, lp_h, nout * sizeof(double));
+        if (chi2) std::memcpy(chi2, ch_h, nout * sizeof(double));
+        return VAMP_OK;
+    }
     if (c->sc_th_cap < nth) {
         if (c->sc_th) (void)hipFree(c->sc_th);
         c->sc_th = nullptr; c->sc_th_cap = 0;
