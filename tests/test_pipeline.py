@@ -146,6 +146,15 @@ def test_fit_spectrum_end_to_end_and_cli(tmp_path):
     for s, e in g["CII1036_region_pixels"]:
         mask[s:e] = False
     assert np.all(fm["total"][mask] == 1.0)
+    # SURVEY section 5 "Metrics / logging": one JSON perf record per spectrum, on stdout and beside the result files
+    import json
+    lines = [ln for ln in rc.stdout.splitlines() if ln.startswith("vamp_perf ")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0][len("vamp_perf "):])
+    assert rec["spectrum"] == "spectrum_7.h5" and rec["regions"] == 4 and rec["lines"] == n and rec["seconds"] > 0
+    assert rec["voigt"] is False and rec["batched"] is False and rec["median_reduced_chi2"] > 0
+    assert rec["pixels_in_regions"] == int(sum(e - s for s, e in g["CII1036_region_pixels"]))
+    assert json.load(open(out / "spectrum_7_gauss_perf.json")) == rec
 
 
 @pytest.mark.gpu
