@@ -499,6 +499,12 @@ def main():
     dt = time.perf_counter() - t0
     x_ms, x_n = ctx.exchange_timing()
     k_ms, k_n = ctx.kernel_timing(False)
+    if dist is not None:
+        # the max over ranks NOW: the length of the second run is derived from it, and every rank must step the
+        # same number of times (a rank that ran one step more would wait in the exchange for ever)
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
 
     # a longer second run (clocks and caches settled; 20 steps are 0.15 s): same loop, the chain thinned
     # into the same buffer
@@ -517,12 +523,10 @@ def main():
         s_ms, s_n = ctx.kernel_timing(False)
         sustained = {"steps": n_s, "seconds": dts, "chain_thin": thin, "avg_launch_ms": s_ms / max(1, s_n), "launches": s_n}
 
-    if dist is not None:
-        t = torch.tensor([dt, sustained["seconds"] if sustained else 0.0], dtype=torch.float64)
+    if dist is not None and sustained:
+        t = torch.tensor([sustained["seconds"]], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-        if sustained:
-            sustained["seconds"] = float(t[1])
+        sustained["seconds"] = float(t[0])
 
     # sanity: the ensemble is alive (some proposals accepted, lnprob finite)
     _, lnp, nacc, n_done = ctx.get_state()

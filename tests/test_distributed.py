@@ -519,8 +519,9 @@ def test_pieces_of_a_packed_single_region_ensemble():
 
 # ---- round 3: bench.py as the driver runs it, fall-back safety net, call order, shape under sharding ----
 FAKE_RCCL = os.path.join(ROOT, "tests", "host", "librccl_fake.so")
+# (a short second run too: its length is derived from the timed run, and every rank must derive the same one)
 BENCH_SMALL = ["--walkers", "4096", "--pixels", "2048", "--components", "6", "--steps", "2", "--warmup", "1",
-               "--no-cpu-baseline", "--sustain-seconds", "0"]
+               "--no-cpu-baseline", "--sustain-seconds", "0.2"]
 
 
 def _run_bench(extra_args, extra_env, timeout=600):
@@ -560,6 +561,7 @@ def test_bench_plain_form_launches_its_own_ranks(n):
     assert ex["bytes_per_rank_per_half_step"] == (4096 // n // 2) * (18 + 1) * 8
     assert line["value"] > 0 and 0.05 < line["acceptance_fraction"] < 0.95 and line["finite_lnprob_fraction"] == 1.0
     assert line["roofline"]["walker_steps_per_launch"] == 4096 // n // 2 // ex["parts"]
+    assert line["sustained"]["steps"] >= 2 and line["sustained"]["value"] > 0
 
 
 @pytest.mark.gpu
