@@ -14,9 +14,13 @@ import vamp_amd                                   # noqa: E402
 from oracle import vamp_oracle as vo              # noqa: E402
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+# a second argument "f32": the fp32 path (Taylor rows + W4 wings + 8-node far field under packing 0 / 256, W4 everywhere
+# under 64) against the fp64 oracle at SURVEY 8d's fp32 tolerance, |delta chi^2| / chi^2 <= 1e-3 (lnprob is -chi^2/2 + prior)
+F32 = len(sys.argv) > 2 and sys.argv[2] == "f32"
+TOL = 1e-3 if F32 else 1e-9
 worst = {}
 for packing in (0, 64, 256):
-    ctx = vamp_amd.HipContext(device=0)
+    ctx = vamp_amd.HipContext(device=0, dtype=vamp_amd.F32 if F32 else vamp_amd.F64)
     ctx.set_packing(packing)
     w = 0.0
     for seed in range(n_seeds):
@@ -54,10 +58,10 @@ for packing in (0, 64, 256):
         if fin.any():
             err = np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))
             w = max(w, err.max())
-            if err.max() > 1e-9:
+            if err.max() > TOL:
                 print("FAIL", packing, seed, P, K, kind, err.max(), flush=True)
     worst[packing] = w
     ctx.close()
     print(f"packing {packing}: worst relative lnprob error over {n_seeds} seeds {w:.3e}", flush=True)
-assert max(worst.values()) <= 1e-9
+assert max(worst.values()) <= TOL
 print("soak ok")

@@ -845,6 +845,49 @@ def test_full_size_dispersed_walkers_fp32(packing):
     assert np.max(np.abs(chi[fin] - chi_ref[fin]) / chi_ref[fin]) <= 1e-3, packing
 
 
+@pytest.mark.parametrize("seed", [8, 10, 53, 58, 108])
+def test_fp32_heavily_damped_lines_in_the_far_field(seed):
+    """Regression (round 3, found by tests/soak_long_regions.py f32): a line with a sub-pixel Gaussian width and a
+    Lorentzian width of hundreds of pixels has y = L sqrt(ln 2) / G ~ 1e4 -- a broad Lorentzian with a large optical
+    depth far from its centre.  In the far-field node pass the lanes of a wavefront hold different lines and share one
+    W4 region; region II used to clamp x at 3e4 to keep |t|^8 finite, which for such a line is not a no-op, and the
+    log-posterior was off by up to 44 %.  The soak's regions for the seeds that failed, both fp32 launch shapes."""
+    import vamp_amd
+    rng = np.random.default_rng(7000 + seed)
+    P = int(rng.choice([512, 768, 1300, 2048, 2560, 4096, 6144]))
+    K = int(rng.integers(1, 17))
+    kind = seed % 4
+    if kind == 0:
+        x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+    elif kind == 1:
+        x = np.cumsum(rng.uniform(0.5, 1.5, P))
+    elif kind == 2:
+        x = np.cumsum(np.geomspace(1.0, 3.0, P))
+    else:
+        x = -(np.arange(P, dtype=np.float64) - (P - 1) / 2.0) * 0.37
+    x = x - x.mean()
+    span = abs(x[-1] - x[0])
+    W = 8
+    th = np.empty((W, K, 4))
+    th[:, :, 0] = 10.0 ** rng.uniform(-2, 1.7, (W, K))
+    th[:, :, 1] = rng.uniform(min(x[0], x[-1]), max(x[0], x[-1]), (W, K))
+    th[:, :, 2] = 10.0 ** rng.uniform(-6, np.log10(0.4 * span), (W, K))
+    th[:, :, 3] = 10.0 ** rng.uniform(-1.3, np.log10(0.4 * span), (W, K))
+    th = th.reshape(W, 4 * K)
+    noise = np.full(P, 0.05)
+    flux = np.clip(1.0 + rng.normal(0, 0.05, P), 0, None)
+    r = vo.Region(x=x, flux=flux, noise=noise, n_comp=K, mode=vo.MODE_VOIGT4)
+    want = vo.log_prob_batch_fast(r, th)
+    for packing in (64, 256):
+        with vamp_amd.HipContext(device=0, dtype=vamp_amd.F32) as ctx:
+            ctx.set_packing(packing)
+            ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
+            got = ctx.lnprob(th)
+        assert np.array_equal(np.isfinite(want), np.isfinite(got))
+        fin = np.isfinite(want)
+        assert np.max(np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))) <= 1e-3, (seed, packing)
+
+
 def test_regions_of_more_than_16_lines(hip_ctx):
     """The reference sets no limit on the lines of a region (it plans for more than 15 and more than
     22.5, vpspectrum.py:287-294); the fast launch shapes hold 16, regions of 17 .. 32 lines

@@ -652,7 +652,12 @@ VAMP_DEV float w4_region1(float x, float y) {
     return cdiv_re(cscale(t, 0.5641896f), cadd(u, 0.5f));
 }
 VAMP_DEV float w4_region2(float x, float y) {
-    x = fminf(x, 3.0e4f);                  // |d|^2 ~ x^8 must stay finite; region I takes over in value
+    // |d|^2 ~ |t|^8 must stay inside the fp32 range: beyond |x| + y = 1e3 region I is exact to 1e-12 of the value and
+    // takes over.  (Clamping x instead -- as this function did until round 3 -- is wrong for a heavily damped line:
+    // with y ~ 1e4 the profile y / (x^2 + y^2) is still falling at x = 3e4.  Callers choose the region for a whole
+    // wavefront, and in the far-field node pass the lanes of a wavefront hold DIFFERENT lines, so a lane can arrive
+    // here with any s >= 5.5: tests/soak_long_regions.py f32, test_fp32_heavily_damped_lines_in_the_far_field.)
+    if (x + y >= 1.0e3f) return w4_region1(x, y);
     const cf32 t = {y, -x};
     const cf32 u = cmul(t, t);
     const cf32 n = cmul(t, cadd(cscale(u, 0.5641896f), 1.410474f));
