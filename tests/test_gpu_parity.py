@@ -1011,3 +1011,18 @@ def test_long_region_symmetries(hip_ctx):
     assert np.allclose(chi2(-x, f, n, t), base, rtol=2e-11)
     t = th.copy(); t[:, :, 1] = -t[:, :, 1] + 5.5
     assert np.allclose(chi2((-x + 5.5)[::-1].copy(), f[::-1].copy(), n[::-1].copy(), t), base, rtol=2e-11)
+
+
+@pytest.mark.parametrize("script,args", [("soak_long_regions.py", ["24"]), ("soak_long_regions.py", ["24", "f32"]),
+                                         ("soak_short_regions.py", ["10"]), ("soak_short_regions.py", ["10", "f32"])])
+def test_soaks_in_short(script, args):
+    """The developer soaks (tests/soak_*.py: random long and short regions with widths and dampings over decades,
+    every packing, fp64 at 1e-9 and fp32 at 1e-3 against the oracle) over a few seeds on every GPU test run; the
+    fp32 long-region soak is what found the W4 region II clamp in round 3."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", script)] + args, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "soak ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
