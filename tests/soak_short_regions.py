@@ -22,13 +22,13 @@ C_LIGHT, SIGMA0, LINE, PIX_HZ = 2.98e8, 0.0263, 1215.67, 4.0e10          # physi
 FWHM_PER_SIGMA = 2.0 * np.sqrt(2.0 * np.log(2.0))
 
 
-def make(rng, n_regions, W, variant):
+def make(rng, n_regions, W, variant, kmin=1, kmax=8):
     """variant 0: (amplitude, centroid, L, G); 1: Gaussian components; 2: variant 0 with the reference's free
     precision sd as last dimension (vpfits.py:39); 3: (N, b, z) through the reference's maps"""
     xs, fs, ns, Ks, ths, regs, nbzs = [], [], [], [], [], [], []
     for _ in range(n_regions):
         P = int(rng.choice([9, 14, 23, 36, 51, 64, 65, 97, 130, 200, 256, 257, 330, 478, 512]))
-        K = int(rng.integers(1, 9))
+        K = int(rng.integers(kmin, kmax + 1))
         x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
         if rng.random() < 0.3:
             x = np.cumsum(rng.uniform(0.7, 1.3, P))
@@ -72,14 +72,16 @@ def make(rng, n_regions, W, variant):
 
 
 worst = {}
-for packing, W in ((0, 64), (16, 64), (64, 64), (65, 64), (0, 16384)):
+# (packing, walkers, lines per region): the last two rows are regions of 17 .. 32 lines (their own launch class)
+for packing, W, (kmin, kmax) in ((0, 64, (1, 8)), (16, 64, (1, 8)), (64, 64, (1, 8)), (65, 64, (1, 8)), (0, 16384, (1, 8)),
+                                 (0, 280, (9, 32)), (64, 280, (17, 32))):
     w = 0.0
     for c in range(n_ctx if W == 64 else max(1, n_ctx // 10)):
         rng = np.random.default_rng(9000 + c)
         variant = c % 4
         if F32 and variant == 1:
             variant = 0                              # (Gaussian components have no W4 path to test)
-        xs, fs, ns, Ks, ths, regs, nbz, kw = make(rng, 8 if W == 64 else 3, W, variant)
+        xs, fs, ns, Ks, ths, regs, nbz, kw = make(rng, 8 if W == 64 else 3, W, variant, kmin, kmax)
         ctx = vamp_amd.HipContext(device=0, dtype=vamp_amd.F32 if F32 else vamp_amd.F64)
         ctx.set_packing(packing)
         ctx.set_regions(xs, fs, ns, Ks, nbz=nbz, **kw)
@@ -118,7 +120,7 @@ for packing, W in ((0, 64), (16, 64), (64, 64), (65, 64), (0, 16384)):
                 w = max(w, err.max())
                 if err.max() > TOL:
                     print("FAIL", packing, W, c, variant, r, len(xs[r]), Ks[r], err.max(), flush=True)
-    worst[(packing, W)] = w
-    print(f"packing {packing}, {W} walkers: worst relative {'chi^2' if F32 else 'lnprob'} error {w:.3e}", flush=True)
+    worst[(packing, W, kmax)] = w
+    print(f"packing {packing}, {W} walkers, {kmin}..{kmax} lines: worst relative {'chi^2' if F32 else 'lnprob'} error {w:.3e}", flush=True)
 assert max(worst.values()) <= TOL
 print("soak ok")
