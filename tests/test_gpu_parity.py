@@ -1014,7 +1014,8 @@ def test_long_region_symmetries(hip_ctx):
 
 
 @pytest.mark.parametrize("script,args", [("soak_long_regions.py", ["24"]), ("soak_long_regions.py", ["24", "f32"]),
-                                         ("soak_short_regions.py", ["10"]), ("soak_short_regions.py", ["10", "f32"])])
+                                         ("soak_short_regions.py", ["10"]), ("soak_short_regions.py", ["10", "f32"]),
+                                         ("soak_sampler.py", ["8"])])
 def test_soaks_in_short(script, args):
     """The developer soaks (tests/soak_*.py: random long and short regions with widths and dampings over decades,
     every packing, fp64 at 1e-9 and fp32 at 1e-3 against the oracle) over a few seeds on every GPU test run; the
