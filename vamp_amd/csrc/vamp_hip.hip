@@ -434,6 +434,12 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
 #endif
 constexpr int TPIX = VAMP_TPIX;      // pixels per lane per iteration in full tiles (the tail of a
                                      // region runs one pixel per lane, so short regions waste nothing)
+#ifndef VAMP_SMALL_TPIX
+#define VAMP_SMALL_TPIX 4
+#endif
+// several walkers per wavefront: pixels per lane and iteration (each near-axis evaluation in flight holds ~40 VGPRs)
+template <class PK>
+constexpr int pixels_per_lane() { return PK::SUBS > 1 ? VAMP_SMALL_TPIX : TPIX; }
 
 template <int M, int T>
 __device__ __forceinline__ void tile_jfrac(const double (&X)[T], const double (&r2)[T], double y, double (&H)[T]) {
@@ -1172,6 +1178,7 @@ template <bool F32, int MODE, class PK, bool TAB = use_tables<F32, MODE, PK>()>
 __device__ __forceinline__ void sweep_class(const RegionDev& R, const typename PK::Lds& L, TileScratch& Sx, const double* __restrict__ dct,
                                             const PixPtrs& px, int lane, int base0, int full, int stride, bool tail, double& chi,
                                             const double* tab) {
+    constexpr int TPIX = pixels_per_lane<PK>();      // (shadows the global: packed shapes may hold fewer pixels per lane)
     if constexpr (F32) {
         const float* x = px.xf + R.pix_off; const float* f = px.ff + R.pix_off; const float* wt = px.wtf + R.pix_off;
         if constexpr (VAMP_FARFIELD && PK::FF && MODE != VAMP_GAUSS3 && TPIX == 4)
@@ -1181,14 +1188,14 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const typename P
         if constexpr (PK::TAIL || TPIX == 1)
             if (tail) {
                 const int from = TPIX > 1 ? full : 0;
-                if constexpr (!PK::FF && TPIX == 4) {
-                    // short regions are all "tail": one iteration with just enough pixels per lane (1..4
+                if constexpr (!PK::FF && TPIX > 1) {
+                    // short regions are all "tail": one iteration with just enough pixels per lane (1..TPIX
                     // independent evaluation chains, all pixel loads in flight together) instead of up
-                    // to four dependent one-pixel rounds
+                    // to TPIX dependent one-pixel rounds
                     const int nt = (R.P - from + PK::LPW - 1) / PK::LPW;
-                    if (nt == 4) sweep_range_f32<MODE, PK, 4>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi);
-                    else if (nt == 3) sweep_range_f32<MODE, PK, 3>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi);
-                    else if (nt == 2) sweep_range_f32<MODE, PK, 2>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi);
+                    if constexpr (TPIX >= 4) { if (nt == 4) sweep_range_f32<MODE, PK, 4>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi); }
+                    if constexpr (TPIX >= 3) { if (nt == 3) sweep_range_f32<MODE, PK, 3>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi); }
+                    if (nt == 2) sweep_range_f32<MODE, PK, 2>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi);
                     else if (nt == 1) sweep_range_f32<MODE, PK, 1>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi);
                 } else {
                     sweep_range_f32<MODE, PK, 1>(R, L, x, f, wt, lane, from, R.P, PK::LPW, chi);
@@ -1202,11 +1209,11 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const typename P
         if constexpr (PK::TAIL || TPIX == 1)
             if (tail) {
                 const int from = TPIX > 1 ? full : 0;
-                if constexpr (!PK::FF && TPIX == 4) {
+                if constexpr (!PK::FF && TPIX > 1) {
                     const int nt = (R.P - from + PK::LPW - 1) / PK::LPW;      // see the fp32 branch
-                    if (nt == 4) sweep_range<MODE, PK, 4, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab);
-                    else if (nt == 3) sweep_range<MODE, PK, 3, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab);
-                    else if (nt == 2) sweep_range<MODE, PK, 2, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab);
+                    if constexpr (TPIX >= 4) { if (nt == 4) sweep_range<MODE, PK, 4, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab); }
+                    if constexpr (TPIX >= 3) { if (nt == 3) sweep_range<MODE, PK, 3, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab); }
+                    if (nt == 2) sweep_range<MODE, PK, 2, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab);
                     else if (nt == 1) sweep_range<MODE, PK, 1, TAB>(R, L, x, f, wt, lane, from, from + 1, 1 << 28, chi, tab);
                 } else {
                     sweep_range<MODE, PK, 1, TAB>(R, L, x, f, wt, lane, from, R.P, PK::LPW, chi, tab);
@@ -1343,7 +1350,7 @@ __device__ __forceinline__ double sweep_blend32(const RegionDev& R, const typena
 template <bool F32, int MODE, class PK = PackWide>
 __device__ __forceinline__ double sweep_pixels(const RegionDev& R, const typename PK::Lds& L, TileScratch& Sx, const double* __restrict__ dct,
                                                const PixPtrs& px, int lane, int part, double* red, const double* tab) {
-    constexpr int TILE = PK::LPW * TPIX;
+    constexpr int TILE = PK::LPW * pixels_per_lane<PK>();
     const int full = (R.P / TILE) * TILE;
     if constexpr (PK::SUBS > 1) {            // several walkers per wavefront: short regions, one pass
         double chi = 0.0;
