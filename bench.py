@@ -416,9 +416,21 @@ def main():
     exchange_label, exchange_kind = "none", "none"
     want = "rccl" if dist is not None else "none"
 
+    class CommunicatorFailed(Exception):
+        """VampError(-3) out of the ShardedEnsemble CONSTRUCTOR: the one failure every rank is known to see together
+        (vamp_amd/ensemble.py: _join_communicator).  Only this leads to the fall-back below; a -3 from a later
+        collective (run_dev in the parts probe) may hit one rank alone and must end the run, not desynchronise it."""
+
     def build(parts, kind=want):
-        return ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange=kind, parts=parts,
-                               exchange_single_rank=args.force_dist)
+        try:
+            return ShardedEnsemble(ctx, wl["theta0"], seed=20240517, dist=dist, exchange=kind, parts=parts,
+                                   exchange_single_rank=args.force_dist)
+        except vamp_amd._lib.VampError as e:
+            if e.code != -3 or dist is None or kind != "rccl":
+                raise
+            err = CommunicatorFailed(str(e))
+            err.stuck = getattr(e, "stuck", False)
+            raise err from e
 
     def sync_all():
         ctx.synchronize()
@@ -455,9 +467,7 @@ def main():
                 parts_tried[p] = float(t[0]) / n_try * 1e3
             best = min(parts_tried, key=parts_tried.get)
             ens = build(best)
-    except vamp_amd._lib.VampError as e:
-        if e.code != -3 or dist is None:  # anything but a communicator problem is a bug: fail
-            raise
+    except CommunicatorFailed as e:
         # ShardedEnsemble raises this on EVERY rank together (vamp_amd/ensemble.py: _join_communicator), so all
         # ranks arrive here: the host-staged exchange -- same kernels, rows through pinned host memory and gloo --
         # is slow and loudly labelled, but the scaling run still produces a correct line instead of none

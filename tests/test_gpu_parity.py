@@ -497,6 +497,42 @@ def test_config5_q1422_regions_fp32_vs_fp64_oracle(packing):
     print("config 5: worst relative chi^2 error over 421 regions x %d walkers: %.2e" % (W, worst))
 
 
+@pytest.mark.parametrize("packing", [0, 16])
+def test_config3_q1422_all_regions_fp64_vs_oracle(packing):
+    """BASELINE.json config 3 on its own workload, the parity path: ALL 421 detected regions of the q1422
+    spectrum in ONE fp64 launch (every launch class: blends with Taylor tables, one- and two-line regions,
+    the rest) against the scipy.wofz oracle, region by region -- |delta lnprob| <= 1e-9 max(1, |lnprob|) and
+    chi^2 to 1e-11 relative for every (region, walker), identical -inf pattern.  W = 8 walkers per region run
+    one walker per wavefront (and per-walker tables for the blends); W = 16 under packing 16 runs four
+    walkers per wavefront."""
+    import vamp_amd
+    from tools.bench_c3 import build_regions, start_walkers
+    xs, fs, ns, ks = build_regions()
+    assert len(xs) == 421 and sum(len(x) for x in xs) == 27536 and max(ks) <= 8
+    rng = np.random.default_rng(1422)
+    W = 8 if packing == 0 else 16
+    thetas = [start_walkers(rng, x, k, W) for x, k in zip(xs, ks)]
+    ctx = vamp_amd.HipContext(device=0, dtype=vamp_amd.F64)
+    try:
+        ctx.set_packing(packing)
+        ctx.set_regions(xs, fs, ns, ks, mode=vamp_amd.MODE_VOIGT4)
+        got, chi = ctx.lnprob_all(thetas, return_chi2=True)
+    finally:
+        ctx.close()
+    worst = worst_chi = 0.0
+    for r, (x, f, n, k) in enumerate(zip(xs, fs, ns, ks)):
+        reg = vo.Region(x=x, flux=f, noise=n, n_comp=k, mode=vo.MODE_VOIGT4)
+        want, wchi = vo.log_prob_batch(reg, thetas[r], return_chi2=True)
+        fin = np.isfinite(want)
+        assert np.array_equal(fin, np.isfinite(got[r])), r
+        err = np.abs(got[r][fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))
+        rel = np.abs(chi[r][fin] - wchi[fin]) / wchi[fin]
+        worst, worst_chi = max(worst, err.max(initial=0.0)), max(worst_chi, rel.max(initial=0.0))
+        assert err.max(initial=0.0) <= 1e-9, (r, len(x), k, err.max())
+        assert rel.max(initial=0.0) <= 1e-11, (r, len(x), k, rel.max())
+    print("config 3: worst lnprob error %.2e, worst relative chi^2 error %.2e over 421 regions x %d walkers" % (worst, worst_chi, W))
+
+
 def test_full_size_properties(hip_ctx):
     """Headline shape (P = 16384, K = 16; fewer walkers): properties that need no CPU reference.
     (1) batch-position independence, (2) component-permutation invariance, (3) tau is the sum of

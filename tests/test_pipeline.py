@@ -210,6 +210,71 @@ def test_fit_spectrum_batched_matches_sequential_shape(tmp_path):
     assert np.all(sp.flux_model["total"] <= 1.0 + 1e-12)
 
 
+@pytest.mark.gpu
+def test_fit_spectrum_fp32_reaches_the_fp64_fit(tmp_path):
+    """BASELINE.json config 5 through the drop-in surface: ``VPspectrum(dtype="f32").fit_spectrum(batched=True)``
+    runs every ladder, ensemble and MAP search of the C II spectrum on the fp32 / Humlicek-W4 kernels.  The
+    chains differ from the fp64 run's (accept decisions within 1e-4 of the threshold flip), so the comparison
+    is between FITS: per region the best reduced chi^2 -- always scored on the host from the fp64 model of the
+    optimum (k_model is fp64 in every context) -- agrees with the fp64 fit's within 25 % or 0.25, and both
+    beat the flat continuum five-fold; the optimum's own fp32 log-posterior is within SURVEY 8d's 1e-3 of
+    its fp64 value.  ``$VAMP_DTYPE`` selects the same path for callers that pass no dtype."""
+    import vamp_amd
+    from vamp_amd.vpspectrum import VPspectrum
+    g = load_golden("simba_spectra.npz")
+    fits = {}
+    for dt in ("f64", "f32"):
+        sp = VPspectrum(1036.3367, voigt=True, nwalkers=32, iterations=400, thin=5, burn=150, seed=11, verbose=False, dtype=dt,
+                        convergence_attempts=2)
+        sp.set_arrays(g["CII1036_wavelength"], g["CII1036_flux"], g["CII1036_noise"])
+        sp.fit_spectrum(batched=True)
+        assert all(r.fit._ctx.dtype == (vamp_amd.F32 if dt == "f32" else vamp_amd.F64) for r in sp.regions)
+        fits[dt] = sp
+    for r64, r32 in zip(fits["f64"].regions, fits["f32"].regions):
+        flat = r64.fit.ReducedChisquared(r64.flux_array, np.ones_like(r64.flux_array), r64.noise_array, r64.freedom)
+        assert r64.best_chi_squared < 0.2 * flat and r32.best_chi_squared < 0.2 * flat
+        assert abs(r32.best_chi_squared - r64.best_chi_squared) <= 0.25 * max(1.0, r64.best_chi_squared), \
+            (r64.n, r32.n, r64.best_chi_squared, r32.best_chi_squared)
+    # the fp32 optimum of every region, re-scored by an fp64 context: SURVEY 8d's |delta chi^2| / chi^2 <= 1e-3
+    regs = fits["f32"].regions
+    with vamp_amd.HipContext(device=0, dtype="f64") as c64, vamp_amd.HipContext(device=0, dtype="f32") as c32:
+        for c in (c64, c32):
+            c.set_regions([r.fit._x for r in regs], [r.flux_array for r in regs], [np.ones_like(r.flux_array) for r in regs],
+                          [r.n for r in regs], mode=vamp_amd.MODE_VOIGT4, sample_sd=True)
+        th = [r.fit._theta_dev[None, :] for r in regs]
+        l64, s64 = c64.lnprob_all(th, return_chi2=True)
+        l32, s32 = c32.lnprob_all(th, return_chi2=True)
+    assert np.all(np.isfinite(l64)) and np.all(np.abs(s32 - s64) <= 1e-3 * s64), (s32, s64)
+
+
+def test_dtype_resolution_and_cli_flags(monkeypatch):
+    """SURVEY section 5 "Config / flags": --dtype / --backend on the CLI, VAMP_DTYPE / VAMP_BACKEND in the
+    environment; an explicit argument wins over the environment (host logic only)."""
+    from vamp_amd import hip_backend as hb
+    monkeypatch.delenv("VAMP_DTYPE", raising=False)
+    assert hb.resolve_dtype(None) == hb.F64 and hb.resolve_dtype("f32") == hb.F32 and hb.resolve_dtype(1) == hb.F32
+    assert hb.resolve_dtype("F64") == hb.F64 and hb.resolve_dtype(hb.F64) == hb.F64
+    monkeypatch.setenv("VAMP_DTYPE", "f32")
+    assert hb.resolve_dtype(None) == hb.F32 and hb.resolve_dtype("f64") == hb.F64
+    with pytest.raises(ValueError):
+        hb.resolve_dtype("f16")
+    from vamp_amd.vpspectrum import VPspectrum
+    from vamp_amd.vpregion import VPregion
+    assert VPspectrum(1215.67).dtype == hb.F32 and VPspectrum(1215.67, dtype="f64").dtype == hb.F64
+    x = np.linspace(1.0, 2.0, 30)
+    assert VPregion(x, np.ones(30), np.full(30, 0.01), dtype="f32").dtype == "f32"
+    # the CLI: parsed flags reach fit_one (stubbed), a foreign backend is refused
+    from vamp_amd import do_vamp
+    seen = {}
+    monkeypatch.setattr(do_vamp, "fit_one", lambda path, args, device=0: seen.update(dtype=args.dtype, backend=args.backend))
+    monkeypatch.setattr(do_vamp.os.path, "isfile", lambda p: True)
+    assert do_vamp.main(["spec.h5", "1215.67", "--dtype", "f32"]) == 0 and seen == {"dtype": "f32", "backend": "hip"}
+    assert do_vamp.main(["spec.h5", "1215.67"]) == 0 and seen["dtype"] is None
+    monkeypatch.setenv("VAMP_BACKEND", "cpu")
+    with pytest.raises(SystemExit):
+        do_vamp.main(["spec.h5", "1215.67"])
+
+
 def test_do_vamp_parallel_plan_and_worker_pinning(tmp_path, monkeypatch):
     """The folder branch of do_vamp (reference do_vamp.py:64-96, which never ran): files are dealt
     round-robin to min(parallel, files) spawned workers, worker r is pinned to GPU r % gpus through

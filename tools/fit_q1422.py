@@ -19,21 +19,40 @@ ap.add_argument("--walkers", type=int, default=32)
 ap.add_argument("--max-regions", type=int, default=0)
 ap.add_argument("--voigt", action="store_true")
 ap.add_argument("--attempts", type=int, default=4)
+ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+ap.add_argument("--profile", default=None, help="write a cProfile of fit_spectrum (sorted by total time) to this file")
+ap.add_argument("--dump", default=None, help="save per-region n and best reduced chi^2 to this .npz (to compare two runs)")
+ap.add_argument("--quiet", action="store_true")
 a = ap.parse_args()
 from vamp_amd.vpspectrum import VPspectrum
 q = np.load(os.path.join(ROOT, "tests", "golden", "q1422_spectrum.npz"))
-sp = VPspectrum(1215.67, voigt=a.voigt, convergence_attempts=a.attempts, nwalkers=a.walkers, iterations=a.iterations, thin=5, burn=a.burn, seed=1, verbose=True)
+sp = VPspectrum(1215.67, voigt=a.voigt, convergence_attempts=a.attempts, nwalkers=a.walkers, iterations=a.iterations, thin=5, burn=a.burn, seed=1, verbose=not a.quiet,
+                dtype=a.dtype)
 wl, fl, no = q["wavelength_milli"] / 1000.0, q["flux_micro"] / 1e6, q["noise_micro"] / 1e6
 if a.max_regions:
     end = int(q["region_pixels"][a.max_regions - 1][1]) + 50
     wl, fl, no = wl[:end], fl[:end], no[:end]
 sp.set_arrays(wl, fl, no)
+prof = None
+if a.profile:
+    import cProfile
+    prof = cProfile.Profile()
+    prof.enable()
 t0 = time.perf_counter()
 params = sp.fit_spectrum(batched=True)
 dt = time.perf_counter() - t0
+if prof is not None:
+    import io
+    import pstats
+    prof.disable()
+    buf = io.StringIO()
+    pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(35)
+    open(a.profile, "w").write(buf.getvalue())
 chi = np.array([r.best_chi_squared for r in sp.regions])
 n = np.array([r.n for r in sp.regions])
-out = {"regions": len(sp.regions), "lines": int(n.sum()), "seconds": dt, "median_reduced_chi2": float(np.median(chi)),
+if a.dump:
+    np.savez(a.dump, n=n, chi=chi)
+out = {"dtype": a.dtype, "regions": len(sp.regions), "lines": int(n.sum()), "seconds": dt, "median_reduced_chi2": float(np.median(chi)),
        "frac_regions_chi2_below_1.5": float(np.mean(chi < 1.5)), "n_hist": np.bincount(n).tolist(),
        "difficult_fit": bool(sp.flux_model["difficult_fit"])}
 

@@ -109,11 +109,12 @@ class BatchedRegionLadder:
     """``VPregion.region_fit`` for a list of ``VPregion`` objects, all rungs of all regions batched.
     After ``run()`` every region has ``.fit`` and ``.n`` as after the reference's ``region_fit``."""
 
-    def __init__(self, regions, nwalkers=64, iterations=3000, thin=15, burn=300, seed=0, device=0, verbose=True, ctx=None):
+    def __init__(self, regions, nwalkers=64, iterations=3000, thin=15, burn=300, seed=0, device=0, verbose=True, ctx=None,
+                 dtype=None):
         self.regions = list(regions)
         self.nwalkers, self.iterations, self.thin, self.burn = nwalkers, iterations, thin, burn
         self.seed, self.verbose = seed, verbose
-        self.ctx = ctx if ctx is not None else hb.HipContext(device=device)
+        self.ctx = ctx if ctx is not None else hb.HipContext(device=device, dtype=dtype)
 
     def _rung(self, idx, rung):
         regs = [self.regions[i] for i in idx]

@@ -6,7 +6,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "vamp_hip.hip")
 OUT = os.path.join(HERE, "libvamp_hip.so")
-DEPS = [SRC, os.path.join(HERE, "csrc", "ff_matrix.inc"), os.path.join(HERE, "csrc", "voigt_math.hpp"), os.path.join(HERE, "csrc", "map_search.hpp"), os.path.join(HERE, "..", "include", "vamp_hip.h")]
+# every file vamp_hip.hip #includes: a regenerated matrix or an edited header must trigger a rebuild
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("ff_matrix.inc", "ff_matrix32.inc", "voigt_math.hpp", "map_search.hpp", "host_plan.hpp")
+                if os.path.exists(os.path.join(HERE, "csrc", f))] + [os.path.join(HERE, "..", "include", "vamp_hip.h")]
 
 
 # -fno-slp-vectorize: left to itself the SLP vectoriser pairs the independent fp32 chains of a lane's four pixels

@@ -2629,7 +2629,8 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         // costs ~2 near-axis evaluations per line and interval, repaid from ~30 px per line on) and
         // the rest, four walkers to a wavefront; everything else is one wide class.
         c->class_of.assign(n_regions, 0);
-        const bool spectrum_like = c->packing == 0 && n_std == n_regions && kmax <= PackSmall::KCAP && mean_p <= 128.0;
+        // (judged over the regions of <= KMAX lines only: a region of 17+ lines has its own class whatever the others run)
+        const bool spectrum_like = c->packing == 0 && n_std > 0 && kmax <= PackSmall::KCAP && mean_p <= 128.0;
         LaunchClass cls[4];
         cls[0].kind = c->packing == 16 ? CK_SMALL : c->packing == 65 ? CK_MID : spectrum_like ? CK_SMALL : CK_WIDE;
         cls[1].kind = CK_MID;

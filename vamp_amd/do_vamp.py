@@ -7,7 +7,8 @@
 branch, do_vamp.py:64-96, calls an undefined function and never ran); worker r runs on GPU
 ``r % gpus`` and pins it with HIP_VISIBLE_DEVICES before anything in that process touches HIP.
 Spectra are independent: no communication.  New flags: --walkers, --iterations, --burn, --thin,
---seed, --batched, --gpus (GPUs to use; default: the GPUs this process can see).
+--seed, --batched, --gpus (GPUs to use; default: the GPUs this process can see), --dtype {f64,f32}
+(per-pixel arithmetic; $VAMP_DTYPE overrides the default), --backend hip ($VAMP_BACKEND).
 """
 import argparse
 import glob
@@ -56,7 +57,8 @@ def perf_record(spec, path, seconds, batched):
             "pixels_in_regions": int(sum(r.num_pixels for r in regs)), "seconds": float(seconds), "batched": bool(batched),
             "sampler_seconds_last_fits": float(sum(fit_s)), "median_reduced_chi2": float(np.median(chi)) if chi.size else None,
             "frac_regions_below_chi_limit": float(np.mean(chi < spec.chi_limit)) if chi.size else None,
-            "difficult_fit": bool(spec.flux_model.get("difficult_fit", False)), "voigt": bool(spec.voigt)}
+            "difficult_fit": bool(spec.flux_model.get("difficult_fit", False)), "voigt": bool(spec.voigt),
+            "dtype": "f32" if getattr(spec, "dtype", 0) == 1 else "f64"}
 
 
 def fit_one(path, args, device=0):
@@ -65,7 +67,7 @@ def fit_one(path, args, device=0):
     from .vpspectrum import VPspectrum
     spec = VPspectrum(args.line, path, args.output_folder, voigt=args.voigt, chi_limit=1.5, mcmc_cov=False,
                       get_mcmc_err=True, convergence_attempts=args.conv_attempts, nwalkers=args.walkers,
-                      iterations=args.iterations, thin=args.thin, burn=args.burn, seed=args.seed)
+                      iterations=args.iterations, thin=args.thin, burn=args.burn, seed=args.seed, dtype=args.dtype, device=device)
     t0 = time.perf_counter()
     params = spec.fit_spectrum(batched=args.batched)
     rec = perf_record(spec, path, time.perf_counter() - t0, args.batched)
@@ -100,9 +102,17 @@ def main(argv=None, _fit_name="vamp_amd.do_vamp:fit_one"):
     p.add_argument("--burn", type=int, default=300)
     p.add_argument("--thin", type=int, default=15)
     p.add_argument("--seed", type=int, default=None)
+    p.add_argument("--dtype", choices=["f64", "f32"], default=None,
+                   help="per-pixel arithmetic of the device kernels: f64 (the reference's; default) or f32 = Humlicek W4 "
+                        "(BASELINE config 5: chi^2 within 1e-3 of fp64); default: $VAMP_DTYPE, else f64")
+    p.add_argument("--backend", choices=["hip"], default=os.environ.get("VAMP_BACKEND", "hip"),
+                   help="compute backend: hip (libvamp_hip.so on a GPU).  There is no CPU backend in the product: "
+                        "oracle/libvamp_cpu.so is test infrastructure")
     p.add_argument("--batched", action="store_true",
                    help="fit all regions of a spectrum together (one kernel launch per half-step for the whole spectrum)")
     args = p.parse_args(argv)
+    if args.backend != "hip":            # (argparse does not check a default taken from the environment)
+        sys.exit("do_vamp: backend %r is not available: the product runs on libvamp_hip.so only (no CPU fallback)" % args.backend)
     if args.output_folder is not None:
         os.makedirs(args.output_folder, exist_ok=True)
         if not args.output_folder.endswith(os.sep):

@@ -17,6 +17,25 @@ F64, F32 = 0, 1
 WOFZ_ACCURATE, WOFZ_HUMLICEK_W4 = 0, 1
 
 
+def resolve_dtype(dtype=None):
+    """F64 / F32 from None, 0 / 1, or "f64" / "f32".  None means: the environment's ``VAMP_DTYPE`` (SURVEY section 5
+    "Config / flags": an override for callers that never pass a type -- the reference's own call sites,
+    vpregion.py:59, vpspectrum.py:279, do_vamp.py:59-60), else fp64, the reference's arithmetic width."""
+    import os
+    if dtype is None:
+        dtype = os.environ.get("VAMP_DTYPE") or F64
+    if isinstance(dtype, str):
+        key = dtype.strip().lower()
+        if key in ("f64", "fp64", "float64", "double", "0"):
+            return F64
+        if key in ("f32", "fp32", "float32", "single", "1"):
+            return F32
+        raise ValueError("dtype must be 'f64' or 'f32', got %r" % (dtype,))
+    if int(dtype) not in (F64, F32):
+        raise ValueError("dtype must be F64 (0) or F32 (1), got %r" % (dtype,))
+    return int(dtype)
+
+
 def _dp(a):
     return a.ctypes.data_as(_lib.c_double_p) if a is not None else None
 
@@ -51,10 +70,12 @@ def default_split_block(W, world=1):
 class HipContext:
     """One device context: regions + (optionally) an ensemble sampler."""
 
-    def __init__(self, device=0, dtype=F64, wofz_kind=None, lib=None):
+    def __init__(self, device=0, dtype=None, wofz_kind=None, lib=None):
         """``lib``: an already bound implementation of the C ABI (``_lib.bind(path)``); the default
-        -- and the only thing the product uses -- is libvamp_hip.so."""
+        -- and the only thing the product uses -- is libvamp_hip.so.  ``dtype``: F64 / F32 / "f64" / "f32";
+        None = $VAMP_DTYPE, else fp64."""
         self._lib = lib if lib is not None else _lib.load()
+        dtype = resolve_dtype(dtype)
         if wofz_kind is None:
             wofz_kind = WOFZ_ACCURATE if dtype == F64 else WOFZ_HUMLICEK_W4
         h = C.c_void_p()

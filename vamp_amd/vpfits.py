@@ -136,7 +136,7 @@ class VPfit():
         self.std_deviation = None if noise is None else 1.0 / self.noise ** 2
         self.verbose = False
         self.device = device
-        self.dtype = hb.F64 if dtype is None else dtype
+        self.dtype = hb.resolve_dtype(dtype)      # None: $VAMP_DTYPE, else fp64 (fp32 = Humlicek W4, BASELINE config 5)
         self._seed = np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0] if seed is not None \
             else np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0]
         self._ctx = None

@@ -20,7 +20,8 @@ MAX_COMPONENTS = 32      # VAMP_MAX_COMPONENTS of include/vamp_hip.h (the refere
 
 class VPregion():
 
-    def __init__(self, frequency_array, flux_array, noise_array, voigt=False, chi_limit=1.5, nwalkers=None, seed=None):
+    def __init__(self, frequency_array, flux_array, noise_array, voigt=False, chi_limit=1.5, nwalkers=None, seed=None,
+                 dtype=None, device=0):
         self.frequency_array = frequency_array
         self.flux_array = flux_array
         self.noise_array = noise_array
@@ -29,6 +30,7 @@ class VPregion():
         self.num_pixels = len(flux_array)
         self.nwalkers = nwalkers
         self._seed = seed
+        self.dtype, self.device = dtype, device    # per-pixel arithmetic of the fits (None: $VAMP_DTYPE, else fp64) and GPU
         self._attempt = 0         # region_fit calls so far: a retry must not replay the previous attempt's draws
         self.estimate_n()
         self.set_freedom()
@@ -45,7 +47,8 @@ class VPregion():
         self.freedom = self.num_pixels - 3 * self.n
 
     def _fit_n(self, n, iterations, thin, burn):
-        fit = VPfit(seed=None if self._seed is None else self._seed + 1000 * n + 1000003 * (self._attempt - 1))
+        fit = VPfit(seed=None if self._seed is None else self._seed + 1000 * n + 1000003 * (self._attempt - 1),
+                    dtype=self.dtype, device=self.device)
         if self.nwalkers is not None:
             fit.nwalkers = self.nwalkers
         fit.find_bic(self.frequency_array, self.flux_array, n, self.noise_array, self.freedom,

@@ -129,9 +129,13 @@ class VPspectrum():
     def __init__(self, line, spectrum_file=None, out_folder=None, voigt=False, chi_limit=1.5, mcmc_cov=False,
                  get_mcmc_err=True, convergence_attempts=10, chi_sq_maximum=10., max_single_region_components=15,
                  ideal_single_region_components=5, min_region_percentage=2., nwalkers=None, iterations=3000, thin=15,
-                 burn=300, seed=None, verbose=True):
-        """Arguments as vpspectrum.py:23-52; nwalkers / iterations / thin / burn / seed / verbose are
-        new and forwarded to the region fits."""
+                 burn=300, seed=None, verbose=True, dtype=None, device=0):
+        """Arguments as vpspectrum.py:23-52; nwalkers / iterations / thin / burn / seed / verbose / dtype / device
+        are new and forwarded to the region fits (dtype: "f64" -- the reference's arithmetic -- or "f32" = the
+        Humlicek-W4 path of BASELINE.json config 5; None: $VAMP_DTYPE, else fp64)."""
+        from . import hip_backend as _hb
+        self.dtype = _hb.resolve_dtype(dtype)
+        self.device = device
         self.line = line
         self.spectrum_file = spectrum_file
         self.out_folder = out_folder
@@ -175,7 +179,8 @@ class VPspectrum():
         n = np.flip(self.noise_array[start:end], 0)
         nu = np.flip(self.frequency_array[start:end], 0)
         return VPregion(nu, f, n, voigt=self.voigt if voigt is None else voigt, chi_limit=self.chi_limit,
-                        nwalkers=self.nwalkers, seed=None if self.seed is None else self.seed + 7 * start)
+                        nwalkers=self.nwalkers, seed=None if self.seed is None else self.seed + 7 * start,
+                        dtype=self.dtype, device=self.device)
 
     def split_difficult_region(self):
         """If the whole spectrum is ONE region that wants more than ``max_single_region_components``
@@ -213,7 +218,8 @@ class VPspectrum():
         Returns the ``params`` dict.  ``batched=True`` runs the BIC ladders of all regions together
         (one kernel launch per half-step for the whole spectrum, vamp_amd/batched.py) with the same
         retry / keep-best loop over the regions still above the chi^2 limit; regions that want more
-        lines than a batch holds (8) are fitted one by one as the reference does."""
+        lines than the packed launch shapes hold (8) form a second ragged batch of up to
+        VAMP_MAX_COMPONENTS = 32 lines each."""
         self.compute_detection_regions(min_region_width=2)
         self.split_difficult_region()
         if batched:
@@ -289,7 +295,7 @@ class VPspectrum():
         # and runs the ladder of the regions whose best reduced chi^2 is still above their limit, with fresh
         # draws; a region keeps the best fit it has seen.  Two batches, by the launch shapes they run on: regions
         # that want <= BATCH_MAX_LINES lines (the packed shapes of real spectra) and the few that want more (a
-        # wavefront per walker, up to the kernels' 16 lines) -- those are NOT clamped to 8 and retried against an
+        # second ragged batch, a wavefront per walker, up to VAMP_MAX_COMPONENTS = 32 lines) -- those are NOT clamped to 8 and retried against an
         # unscaled limit: as in the reference a region beyond max_single_region_components is flagged
         # difficult_fit, gets 2 attempts (1 beyond 1.5 x) and three times the chi^2 limit (:287-294, 325-327)
         from .batched import MAX_COMPONENTS
@@ -312,12 +318,16 @@ class VPspectrum():
             pending, attempt = list(group), 0
             while pending:
                 regs = [self.regions[i] for i in pending]
-                for r in regs:
+                limits = {}
+                for i, r in zip(pending, regs):
                     r.estimate_n()
+                    # the limit follows the n ESTIMATED for this attempt, before the ladder grows it (vpspectrum.py:325-327,
+                    # as _fit_region_attempts does)
+                    limits[i] = r.chi_limit * 3 if r.n > self.max_single_region_components else r.chi_limit
                     r.n = min(r.n, cap)
                 ladder = BatchedRegionLadder(regs, nwalkers=self.nwalkers or 64, iterations=self.iterations, thin=self.thin,
                                              burn=self.burn, seed=(self.seed or 0) + 7727 * attempt + (0 if cap == BATCH_MAX_LINES else 15485863),
-                                             verbose=self.verbose, ctx=ctx)
+                                             verbose=self.verbose, ctx=ctx, dtype=self.dtype, device=self.device)
                 ctx = ladder.ctx
                 ladder.run()
                 still = []
@@ -326,9 +336,8 @@ class VPspectrum():
                     chi = region.fit.ReducedChisquared(region.flux_array, region.fit.total.value, region.noise_array, region.freedom)
                     if i not in best or chi < best[i][0]:
                         best[i] = (chi, region.fit)
-                    limit = region.chi_limit * 3 if region.n > self.max_single_region_components else region.chi_limit
                     left[i] -= 1
-                    if not (best[i][0] < limit) and left[i] > 0:
+                    if not (best[i][0] < limits[i]) and left[i] > 0:
                         still.append(i)
                 attempt += 1
                 if self.verbose:
