@@ -49,7 +49,7 @@ enum vamp_dtype { VAMP_F64 = 0, VAMP_F32 = 1 };          /* per-pixel arithmetic
 enum vamp_wofz { VAMP_WOFZ_ACCURATE = 0, VAMP_WOFZ_HUMLICEK_W4 = 1 };
 
 #define VAMP_MAX_COMPONENTS 32
-#define VAMP_ABI_VERSION 3
+#define VAMP_ABI_VERSION 4
 #define VAMP_COMM_ID_BYTES 128   /* = NCCL_UNIQUE_ID_BYTES */
 
 /* library identification */
@@ -69,6 +69,16 @@ int vamp_ctx_destroy(vamp_ctx* ctx);
 int vamp_ctx_set_stream(vamp_ctx* ctx, void* hip_stream);
 int vamp_ctx_set_stream_default(vamp_ctx* ctx);
 int vamp_ctx_synchronize(vamp_ctx* ctx);
+/* Run-time switches of a context (all default to 1); an unknown name is VAMP_ERR_ARG.
+ *   "map_device"     1: vamp_map_all runs every region's whole Nelder-Mead search in one launch (one workgroup
+ *                    per region); 0: the host drives the same search, one launch + one synchronisation per
+ *                    iteration of all regions.  Same rules, same arithmetic: identical results.
+ *   "resident"       1: vamp_sampler_run(_dev) steps small ensembles (regions whose movers of a half-step fit one
+ *                    workgroup) with the whole step loop inside ONE launch per launch class; 0: always one launch
+ *                    per half-step.  Same draws, same kernels' arithmetic: identical chains.
+ *   "class_streams"  1: the launch classes of a half-step run concurrently on forked streams; 0: one after the
+ *                    other (what the per-class profiles use).  Also set by VAMP_CLASS_STREAMS in the environment. */
+int vamp_ctx_set_option(vamp_ctx* ctx, const char* name, int64_t value);
 /* Lanes that serve one walker:
  *   64   one walker per wavefront;
  *   256  one walker per 4-wavefront workgroup: each wavefront sweeps every 4th 256-pixel tile and, in
@@ -202,6 +212,11 @@ int vamp_comm_destroy(vamp_ctx* ctx);
  * may be NULL.  vamp_comm_init_rank and vamp_sampler_set_shard_parts may come in either order;
  * the second one returns VAMP_ERR_ARG if its rank / world differ from the first one's. */
 int vamp_comm_info(vamp_ctx* ctx, int* rank, int* world, int* queried);
+/* File name of the shared library whose ncclAllGather carries the exchange (dladdr of the bound entry point),
+ * copied into path[capacity]: librccl of the ROCm runtime this library is bound to -- or whatever VAMP_RCCL_LIB
+ * named (the GPU tests' shared-memory stand-in).  bench.py prints it as `exchange.rccl_library`, so that a
+ * scaling line says which library moved its bytes.  VAMP_ERR_COMM when no RCCL can be loaded. */
+int vamp_comm_library(char* path, int64_t capacity);
 /* Restrict this ctx to shard `rank` of `world` equal shards of every half-step's active slots;
  * own_begin / own_end receive the rows of the walkers it owns (whole split chunks).  n_accept is
  * maintained for owned rows only; positions and lnprob are complete on every rank. */

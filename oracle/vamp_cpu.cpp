@@ -18,6 +18,8 @@
 // SURVEY Appendix B.  The independent checker of both libraries is oracle/vamp_oracle.py (scipy.wofz).
 #include <omp.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -377,6 +379,14 @@ int vamp_ctx_destroy(vamp_ctx* c) { delete c; return VAMP_OK; }
 int vamp_ctx_set_stream(vamp_ctx* c, void*) { return c ? VAMP_OK : fail(VAMP_ERR_ARG, "vamp_ctx_set_stream: ctx is NULL"); }
 int vamp_ctx_set_stream_default(vamp_ctx* c) { return c ? VAMP_OK : fail(VAMP_ERR_ARG, "vamp_ctx_set_stream_default: ctx is NULL"); }
 int vamp_ctx_synchronize(vamp_ctx* c) { return c ? VAMP_OK : fail(VAMP_ERR_ARG, "vamp_ctx_synchronize: ctx is NULL"); }
+int vamp_ctx_set_option(vamp_ctx* c, const char* name, int64_t) {
+    // the switches choose between device execution forms with identical results: nothing to switch on the host
+    if (!c || !name) return fail(VAMP_ERR_ARG, "vamp_ctx_set_option: NULL argument");
+    const std::string key(name);
+    if (key != "map_device" && key != "resident" && key != "class_streams")
+        return fail(VAMP_ERR_ARG, "vamp_ctx_set_option: unknown option '" + key + "' (map_device, resident, class_streams)");
+    return VAMP_OK;
+}
 int vamp_ctx_set_packing(vamp_ctx* c, int lanes) {
     if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: ctx is NULL");
     if (lanes != 0 && lanes != 16 && lanes != 64 && lanes != 65 && lanes != 256)
@@ -767,6 +777,14 @@ int vamp_comm_init_rank(vamp_ctx* c, const char* id, int rank, int world) {
     if (c->comm) return fail(VAMP_ERR_STATE, "vamp_comm_init_rank: the context already has a communicator");
     if (world != 1) return fail(VAMP_ERR_COMM, "vamp_comm_init_rank: the host build has no RCCL (exchange through vamp_sampler_pack_get / scatter_put)");
     c->comm = true;
+    return VAMP_OK;
+}
+int vamp_comm_library(char* path, int64_t capacity) {
+    // the host build has no RCCL: its one-rank "communicator" is this library itself
+    if (!path || capacity < 2) return fail(VAMP_ERR_ARG, "vamp_comm_library: no room for a path");
+    Dl_info info;
+    const char* name = (dladdr(reinterpret_cast<void*>(&vamp_comm_library), &info) && info.dli_fname) ? info.dli_fname : "";
+    std::snprintf(path, (size_t)capacity, "%s", name);
     return VAMP_OK;
 }
 int vamp_comm_destroy(vamp_ctx* c) {

@@ -44,7 +44,7 @@ def test_ctypes_table_mirrors_header():
 def test_version_and_error_string(libpath):
     from vamp_amd import _lib
     lib = _lib.load()
-    assert lib.vamp_version() == 3          # VAMP_ABI_VERSION of include/vamp_hip.h
+    assert lib.vamp_version() == 4          # VAMP_ABI_VERSION of include/vamp_hip.h
     assert isinstance(lib.vamp_last_error(), bytes)
     # NULL-argument calls are rejected before any HIP call
     assert lib.vamp_ctx_set_stream(None, None) == -1

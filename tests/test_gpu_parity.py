@@ -742,6 +742,56 @@ def test_map_all_follows_scipy_fmin(hip_ctx):
         assert np.array_equal(la[r], l1) and np.array_equal(ca[r], c1, equal_nan=True)
 
 
+@pytest.mark.parametrize("mode,sd", [(vo.MODE_GAUSS3, True), (vo.MODE_VOIGT4, True), (vo.MODE_VOIGT4, False)])
+def test_map_search_on_device_equals_host_driven(hip_ctx, mode, sd):
+    """The device-resident MAP search (k_map_search: one workgroup per region, the whole Nelder-Mead search in
+    ONE launch, vpfits.py:352-358, 426) against the host-driven search of csrc/map_search.hpp (one launch +
+    one synchronisation per iteration; "map_device" = 0), which test_map_all_follows_scipy_fmin ties to
+    scipy's fmin: same optimum BIT FOR BIT, same iteration count, for every region of a mixed context --
+    short one- and two-line regions, a blend (per-walker Taylor tables), a region of more than 16 lines, an
+    inactive region -- under fmin's default limits (maxfun = 200 per dimension) and under tight ones
+    (maxiter, maxfun hit before convergence; shrink steps happen on the way)."""
+    rng = np.random.default_rng(5 + mode + 2 * sd)
+    shapes = [(30, 1), (44, 2), (51, 4), (160, 3), (23, 1), (90, 6)]
+    if hip_ctx.packing_request == 256:
+        shapes = [(2100, 3), (2300, 5)]
+    elif hip_ctx.packing_request not in (16, 65):
+        shapes.append((120, 18))
+    q = 3 if mode == vo.MODE_GAUSS3 else 4
+    xs, fs, ns, Ks, starts = [], [], [], [], []
+    for P, K in shapes:
+        x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+        c = rng.uniform(x[0] * 0.8, x[-1] * 0.8, K)
+        w = rng.uniform(1.5, 0.08 * P + 2.0, K)
+        tau = sum(rng.uniform(0.3, 2.0) * np.exp(-0.5 * ((x - ck) / wk) ** 2) for ck, wk in zip(c, w))
+        noise = np.full(P, 0.02)
+        xs.append(x); fs.append(np.exp(-tau) + rng.normal(0, 0.02, P)); ns.append(np.ones(P) if sd else noise); Ks.append(K)
+        th = np.empty((K, q))
+        th[:, 0] = rng.uniform(0.2, 1.5, K)
+        th[:, 1] = c + rng.normal(0, 1.0, K)
+        th[:, 2] = w * rng.uniform(0.7, 1.4, K) if q == 3 else rng.uniform(0.2, 2.0, K)
+        if q == 4:
+            th[:, 3] = 2.355 * w * rng.uniform(0.7, 1.4, K)
+        starts.append(np.concatenate([th.ravel(), [0.05]]) if sd else th.ravel())
+    hip_ctx.set_regions(xs, fs, ns, Ks, mode=mode, sample_sd=sd)
+    active = np.ones(len(shapes), dtype=np.uint8)
+    active[1] = 0
+    try:
+        for kw in (dict(iterlim=400, tol=1e-3), dict(iterlim=60, tol=1e-8, xtol=1e-8), dict(iterlim=10 ** 6, tol=1e-9, xtol=1e-9, maxfun=150)):
+            hip_ctx.set_option("map_device", 1)
+            b1, l1, c1, i1 = hip_ctx.map_all(starts, active=active, **kw)
+            hip_ctx.set_option("map_device", 0)
+            b0, l0, c0, i0 = hip_ctx.map_all(starts, active=active, **kw)
+            assert np.array_equal(i1, i0), (kw, i1, i0)
+            for r in range(len(shapes)):
+                assert np.array_equal(b1[r], b0[r]), (kw, r)
+            assert np.array_equal(l1, l0) and np.array_equal(c1, c0, equal_nan=True)
+            assert i1[1] == 0 and np.array_equal(b1[1], starts[1]) and i1[0] > 5
+            assert np.all(l1 >= hip_ctx.lnprob_all([s_[None, :] for s_ in starts])[:, 0])
+    finally:
+        hip_ctx.set_option("map_device", 1)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_random_long_regions_match_oracle(hip_ctx, seed):
     """Seeded random long regions (full tiles + ragged tail, 1-16 lines) with line widths and

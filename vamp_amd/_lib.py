@@ -30,6 +30,8 @@ SIGNATURES = {
     "vamp_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vamp_ctx_set_stream_default": (C.c_int, [C.c_void_p]),
     "vamp_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "vamp_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "vamp_comm_library": (C.c_int, [C.c_char_p, C.c_int64]),
     "vamp_ctx_set_packing": (C.c_int, [C.c_void_p, C.c_int]),
     "vamp_set_regions": (C.c_int, [C.c_void_p, C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_int32_p,
                                    C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),

@@ -16,7 +16,41 @@
 #include <cstdint>
 #include <vector>
 
+#if defined(__HIPCC__)
+#define VAMP_NM_HD __host__ __device__ inline
+#else
+#define VAMP_NM_HD inline
+#endif
+
 namespace vamp {
+
+// ---- the arithmetic of one simplex update, shared by the host search below and the device search
+// (k_map_search in vamp_hip.hip: one workgroup per region, the whole search in ONE launch) ---------------
+// scipy forms these points with numpy, i.e. every product and sum rounded on its own; fused multiply-adds
+// are switched off here so that host and device follow fmin's path to the last bit of the objective.
+// which: 0 reflection, 1 expansion, 2 outside contraction, 3 inside contraction (rho 1, chi 2, psi 1/2)
+VAMP_NM_HD double nm_candidate(int which, double xbar, double worst) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    switch (which) {
+        case 0: return (1.0 + 1.0) * xbar - 1.0 * worst;
+        case 1: return (1.0 + 1.0 * 2.0) * xbar - 1.0 * 2.0 * worst;
+        case 2: return (1.0 + 0.5 * 1.0) * xbar - 0.5 * 1.0 * worst;
+        default: return (1.0 - 0.5) * xbar + 0.5 * worst;
+    }
+}
+// shrink towards the best vertex (sigma 1/2)
+VAMP_NM_HD double nm_shrink(double best, double v) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    return best + 0.5 * (v - best);
+}
+// coordinate k of vertex k + 1 of the start simplex (5 %, or 0.00025 for a zero coordinate)
+VAMP_NM_HD double nm_start_coordinate(double y) { return (y != 0.0) ? (1.0 + 0.05) * y : 0.00025; }
+// f = -lnprob, 1e300 where lnprob is not finite
+VAMP_NM_HD double nm_objective(double lnprob) { return (lnprob - lnprob == 0.0) ? -lnprob : 1e300; }
 
 // dims[r] / offs[r]: dimension of region r and the offset of its vector inside theta0 / theta_best.
 // eval_all(W, theta, lnprob): log-posteriors of W points per region -- theta holds the regions'
@@ -57,11 +91,11 @@ int nelder_mead_all(int R, const int* dims, const long long* offs, const double*
             for (int d = 0; d < s.N; ++d) s.sim[(size_t)k * s.N + d] = x0[d];
         for (int k = 0; k < s.N; ++k) {
             double& y = s.sim[(size_t)(k + 1) * s.N + k];
-            y = (y != 0.0) ? (1.0 + 0.05) * y : 0.00025;
+            y = nm_start_coordinate(y);
         }
     }
     std::vector<double> th, lp;
-    auto objective = [](double v) { return std::isfinite(v) ? -v : 1e300; };
+    auto objective = [](double v) { return nm_objective(v); };
     // evaluate W rows per region; row(r, w) supplies the point (pad rows repeat the best vertex)
     auto evaluate = [&](int W, auto&& row) -> int {
         th.resize((size_t)W * dsum);
@@ -116,10 +150,7 @@ int nelder_mead_all(int R, const int* dims, const long long* offs, const double*
                 double xbar = 0.0;
                 for (int k = 0; k < s.N; ++k) xbar += s.sim[(size_t)k * s.N + d];
                 xbar /= s.N;
-                s.cand[0 * s.N + d] = (1.0 + 1.0) * xbar - 1.0 * worst[d];              // reflection
-                s.cand[1 * s.N + d] = (1.0 + 1.0 * 2.0) * xbar - 1.0 * 2.0 * worst[d];  // expansion
-                s.cand[2 * s.N + d] = (1.0 + 0.5 * 1.0) * xbar - 0.5 * 1.0 * worst[d];  // outside contraction
-                s.cand[3 * s.N + d] = (1.0 - 0.5) * xbar + 0.5 * worst[d];              // inside contraction
+                for (int w = 0; w < 4; ++w) s.cand[w * s.N + d] = nm_candidate(w, xbar, worst[d]);   // reflection, expansion, outside / inside contraction
             }
         }
         if (!any) break;
@@ -154,7 +185,7 @@ int nelder_mead_all(int R, const int* dims, const long long* offs, const double*
                 any_shrink = true;
                 for (int k = 1; k <= s.N; ++k)
                     for (int d = 0; d < s.N; ++d)
-                        s.sim[(size_t)k * s.N + d] = s.sim[d] + 0.5 * (s.sim[(size_t)k * s.N + d] - s.sim[d]);
+                        s.sim[(size_t)k * s.N + d] = nm_shrink(s.sim[d], s.sim[(size_t)k * s.N + d]);
             }
         }
         if (any_shrink) {

@@ -99,6 +99,7 @@ struct RegionDev {
     long long walker_off;  // first global walker id of this region in the sampler state
     long long d_before;    // sum of D over the preceding regions (vamp_lnprob_all: block r starts at W * d_before)
     long long tau_off;     // sum of K * P over the preceding regions (vamp_model_all: this region's tau_comp block)
+    long long sim_off;     // sum of (D + 1) * D over the preceding regions (k_map_search: this region's simplex)
     int P, K, mode, D;     // D = q*K (+1 if sample_sd)
     int sample_sd, q, rng_id, pad1;   // rng_id: the region's identity in the draw keys (default: its index)
     double c_lo, c_hi;     // centroid prior (vpfits.py:250,293)
@@ -1483,6 +1484,195 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_lnprob(
     }
 }
 
+// ---- MAP search on the device (row a9: VPfit.map_estimate / the MAP calls of find_bic, vpfits.py:352-358, 426) -------
+// One workgroup per region runs the WHOLE Nelder-Mead search of that region -- scipy fmin's rules as restated in
+// csrc/map_search.hpp, with the arithmetic of a simplex update shared with it (vamp::nm_*) -- in one launch: the
+// host-driven form of the same search costs one launch + one stream synchronisation per ITERATION (~55 us each,
+// ~60 000 per q1422 fit).  The workgroup has the shape k_lnprob runs for the region's launch class, so a point's
+// objective has the bits vamp_lnprob gives it; its SLOTS walker slots evaluate the candidates of an iteration
+// together (reflection, expansion and both contractions when SLOTS >= 4 -- the speculative form of the host
+// search -- otherwise reflection first and the one point fmin asks for next).  The simplex lives in global
+// scratch ((D + 1) x D doubles per region, L2-resident), values / order / centroid in LDS; the vertices are never
+// moved, `ord` holds their order.  Regions are independent: no inter-workgroup communication.
+constexpr int NM_INIT = 0, NM_CAND = 1, NM_CAND2 = 2, NM_SHRINK = 3;
+struct MapLds {
+    double xbar[DMAX], worst[DMAX];   // centroid of the N best vertices, the worst vertex
+    double f[DMAX + 1];               // objective values, ascending
+    int ord[DMAX + 1];                // ord[k] = row of the k-th best vertex
+    double fv[16];                    // values of the points evaluated in this round, by slot
+    double redx[WAVES_PER_BLOCK], redf[WAVES_PER_BLOCK];
+    double f0;                        // value at the start point
+};
+template <bool F32, int MODE, class PK>
+__global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_map_search(
+    const RegionDev* __restrict__ regions, PixPtrs px, const int* __restrict__ region_list, const double* __restrict__ theta0,
+    const unsigned char* __restrict__ active, long long maxiter, long long maxfun, double xtol, double ftol,
+    double* __restrict__ scratch, double* __restrict__ theta_best, long long* __restrict__ iterations) {
+    constexpr int SLOTS = PK::WALKERS_PER_BLOCK, NT = PK::THREADS;
+    static_assert(SLOTS <= 16 && PK::WPB <= WAVES_PER_BLOCK, "MapLds::fv / redx");
+    __shared__ typename PK::Lds lds[PK::SPLIT ? 1 : PK::WPB * PK::SUBS];
+    __shared__ TileScratch scr[PK::FF ? PK::WPB : 1];
+    __shared__ alignas(16) double dct[PK::FF ? ff_table_doubles<F32>() : 1];
+    __shared__ double red[PARTS];
+    __shared__ LineTables<table_doubles<F32, MODE, PK>()> tabs[PK::SPLIT ? 1 : PK::WPB];
+    __shared__ MapLds M;
+    if constexpr (PK::FF) ff_fill_table<F32>(dct);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int sub = lane / PK::LPW, l = lane % PK::LPW;
+    const int slot = PK::SPLIT ? 0 : wave * PK::SUBS + sub;
+    const int region = region_list ? region_list[blockIdx.x] : (int)blockIdx.x;
+    const RegionDev R = regions[region];
+    const int N = R.D;
+    theta0 += R.d_before;
+    theta_best += R.d_before;
+    if (active && !active[region]) {            // not searched: returned unchanged (uniform over the workgroup)
+        for (int d = tid; d < N; d += NT) theta_best[d] = theta0[d];
+        if (tid == 0) iterations[region] = 0;
+        return;
+    }
+    double* __restrict__ sim = scratch + R.sim_off;            // rows of N doubles: the N + 1 vertices
+    typename PK::Lds& L = lds[slot];
+    // start simplex: the start point and one vertex per coordinate (vamp::nm_start_coordinate)
+    for (int e = tid; e < (N + 1) * N; e += NT) {
+        const int k = e / N, d = e - k * N;
+        const double v = theta0[d];
+        sim[e] = (k >= 1 && d == k - 1) ? vamp::nm_start_coordinate(v) : v;
+    }
+    for (int k = tid; k <= N; k += NT) M.ord[k] = k;
+    const long long fun_cap = maxfun > 0 ? maxfun : 200ll * N;     // scipy's default: 200 evaluations per dimension
+    int phase = NM_INIT, base = 0, need = 0;
+    long long it = 0, calls = 0;
+    for (;;) {
+        __syncthreads();            // the simplex (global), the values and the order (LDS) as the last round left them
+        int n_pts = 0;
+        if (phase == NM_CAND) {
+            // fmin's limits, then its stopping test: max |x_k - x_0| <= xtol and max |f_0 - f_k| <= ftol
+            if (calls >= fun_cap || it + 1 >= maxiter) break;         // fmin counts iterations from 1
+            double mx = 0.0, mf = 0.0;
+            for (int d = tid; d < N; d += NT) {
+                const double r0 = sim[(long long)M.ord[0] * N + d];
+                double sum = 0.0 + r0;          // (the host search starts its sum at +0)
+                for (int k = 1; k < N; ++k) {
+                    const double v = sim[(long long)M.ord[k] * N + d];
+                    sum += v;
+                    mx = fmax(mx, fabs(v - r0));
+                }
+                const double vw = sim[(long long)M.ord[N] * N + d];
+                mx = fmax(mx, fabs(vw - r0));
+                M.xbar[d] = sum / (double)N;
+                M.worst[d] = vw;
+            }
+            for (int k = 1 + tid; k <= N; k += NT) mf = fmax(mf, fabs(M.f[0] - M.f[k]));
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                mx = fmax(mx, __shfl_xor(mx, off, 64));
+                mf = fmax(mf, __shfl_xor(mf, off, 64));
+            }
+            if (lane == 0) { M.redx[wave] = mx; M.redf[wave] = mf; }
+            __syncthreads();
+            mx = M.redx[0]; mf = M.redf[0];
+#pragma unroll
+            for (int w = 1; w < PK::WPB; ++w) { mx = fmax(mx, M.redx[w]); mf = fmax(mf, M.redf[w]); }
+            if (mx <= xtol && mf <= ftol) break;
+            n_pts = SLOTS < 4 ? SLOTS : 4;
+        } else if (phase == NM_CAND2) {
+            n_pts = 1;
+        } else {
+            const int left = (phase == NM_INIT ? N + 1 : N) - base;
+            n_pts = left < SLOTS ? left : SLOTS;
+        }
+        // this slot's point -> its parameter block in LDS, evaluated by the slot's lanes
+        const bool mine = slot < n_pts;
+        if (mine) {
+            if (!PK::SPLIT || wave == 0) {
+                if (phase == NM_CAND || phase == NM_CAND2) {
+                    const int which = phase == NM_CAND ? slot : need;
+                    for (int d = l; d < N; d += PK::LPW) L.theta[d] = vamp::nm_candidate(which, M.xbar[d], M.worst[d]);
+                } else {
+                    const double* row = sim + (long long)M.ord[(phase == NM_INIT ? 0 : 1) + base + slot] * N;
+                    for (int d = l; d < N; d += PK::LPW) L.theta[d] = row[d];
+                }
+            }
+            group_barrier<PK>();
+            const double v = wave_lnprob<F32, MODE, PK>(R, L, scr[PK::FF ? wave : 0], dct, px, l, nullptr, wave, red,
+                                                        tabs[PK::SPLIT ? 0 : wave].a);
+            if (l == 0 && (!PK::SPLIT || wave == 0)) M.fv[slot] = vamp::nm_objective(v);
+        }
+        __syncthreads();
+        // consume the round: every thread takes the same decisions from the same LDS values
+        if (phase == NM_INIT || phase == NM_SHRINK) {
+            const int first = (phase == NM_INIT ? 0 : 1) + base;
+            if (tid < n_pts) M.f[first + tid] = M.fv[tid];
+            base += n_pts;
+            if (base < (phase == NM_INIT ? N + 1 : N)) continue;
+            __syncthreads();
+            if (phase == NM_INIT) calls = N + 1;
+            else { calls += N; it += 1; }
+            if (tid == 0) {
+                if (phase == NM_INIT) M.f0 = M.f[0];
+                for (int i = 1; i <= N; ++i) {              // insertion sort, stable: ties keep their order
+                    const double fi = M.f[i];
+                    const int oi = M.ord[i];
+                    int j = i;
+                    while (j > 0 && fi < M.f[j - 1]) { M.f[j] = M.f[j - 1]; M.ord[j] = M.ord[j - 1]; --j; }
+                    M.f[j] = fi; M.ord[j] = oi;
+                }
+            }
+            phase = NM_CAND;
+            continue;
+        }
+        // NM_CAND / NM_CAND2: fmin's decision; a value this round did not hold is asked for (slots < 4)
+        const int have = phase == NM_CAND ? n_pts : 0;           // candidates 0 .. have - 1 sit in fv[0 .. have)
+        const double f_best = M.f[0], f_second = M.f[N - 1], f_worst = M.f[N];
+        double fr;
+        if (phase == NM_CAND) { fr = M.fv[0]; if (tid == 0) M.redx[0] = fr; }      // (kept for a second round)
+        else fr = M.redx[0];
+        int want;                               // the candidate whose value decides the update
+        if (fr < f_best) want = 1;
+        else if (fr < f_second) want = 0;
+        else if (fr < f_worst) want = 2;
+        else want = 3;
+        double fw;
+        if (want < have) fw = M.fv[want];
+        else if (phase == NM_CAND2) fw = M.fv[0];
+        else { phase = NM_CAND2; need = want; continue; }
+        int take = -1;                          // candidate that replaces the worst vertex, or -1: shrink
+        double ft = 0.0;
+        calls += 1;
+        if (want == 1) { calls += 1; if (fw < fr) { take = 1; ft = fw; } else { take = 0; ft = fr; } }
+        else if (want == 0) { take = 0; ft = fr; }
+        else if (want == 2) { calls += 1; if (fw <= fr) { take = 2; ft = fw; } }
+        else { calls += 1; if (fw < f_worst) { take = 3; ft = fw; } }
+        const int on = M.ord[N];                // row of the worst vertex
+        __syncthreads();                        // (every thread has read fv / redx / f / ord before they change)
+        if (take >= 0) {
+            double* row = sim + (long long)on * N;
+            for (int d = tid; d < N; d += NT) row[d] = vamp::nm_candidate(take, M.xbar[d], M.worst[d]);
+            if (tid == 0) {                     // the new value finds its place among the N others (stable)
+                int j = N;
+                while (j > 0 && ft < M.f[j - 1]) { M.f[j] = M.f[j - 1]; M.ord[j] = M.ord[j - 1]; --j; }
+                M.f[j] = ft; M.ord[j] = on;
+            }
+            it += 1;
+            phase = NM_CAND;
+        } else {
+            for (int e = tid; e < N * N; e += NT) {
+                const int k = 1 + e / N, d = e % N;
+                double* row = sim + (long long)M.ord[k] * N;
+                row[d] = vamp::nm_shrink(sim[(long long)M.ord[0] * N + d], row[d]);
+            }
+            phase = NM_SHRINK;
+            base = 0;
+        }
+    }
+    // the best vertex, unless it is worse than the start point
+    const bool keep_start = M.f[0] > M.f0;
+    const double* best = keep_start ? theta0 : sim + (long long)M.ord[0] * N;
+    for (int d = tid; d < N; d += NT) theta_best[d] = best[d];
+    if (tid == 0) iterations[region] = it;
+}
+
 // tau_k[P] and flux[P] for one parameter vector (one thread per pixel).  region < 0: every region in
 // one launch (blockIdx.y = region): theta holds the regions' D_r-vectors one after the other,
 // tau_comp the [K_r, P_r] blocks one after the other, flux_model is laid out like the pixels.
@@ -1923,6 +2113,14 @@ struct vamp_ctx {
     // kernel reads and writes directly -- no staging copies, one launch and one synchronisation per call
     double *pin_th = nullptr, *pin_out = nullptr;
     size_t pin_th_cap = 0, pin_out_cap = 0;
+    // the MAP searches on the device (k_map_search): start points, flags, simplices, results; grow-only
+    double *map_th_d = nullptr, *map_best_d = nullptr, *map_sim_d = nullptr;
+    unsigned char* map_act_d = nullptr;
+    long long* map_it_d = nullptr;
+    size_t map_th_cap = 0, map_sim_cap = 0, map_r_cap = 0;
+    // run-time options (vamp_ctx_set_option)
+    int opt_map_device = 1;          // 1: vamp_map_all runs k_map_search; 0: the host-driven search, one launch per iteration
+    int opt_resident = 1;            // 1: small ensembles are stepped by the device-resident loop where it applies; 0: never
     // scratch for the ext hook
     int *ext_act_d = nullptr, *ext_par_d = nullptr;
     double *ext_z_d = nullptr, *ext_lu_d = nullptr;
@@ -2459,7 +2657,8 @@ int vamp_ctx_destroy(vamp_ctx* c) {
     free_regions(c);
     for (void* p : {(void*)c->ext_act_d, (void*)c->ext_par_d, (void*)c->ext_z_d, (void*)c->ext_lu_d, (void*)c->sc_th,
                     (void*)c->sc_lp, (void*)c->sc_chi, (void*)c->dr_ws, (void*)c->dr_wc, (void*)c->dr_z, (void*)c->dr_lu,
-                    (void*)c->dr_lz})
+                    (void*)c->dr_lz, (void*)c->map_th_d, (void*)c->map_best_d, (void*)c->map_sim_d, (void*)c->map_act_d,
+                    (void*)c->map_it_d})
         if (p) (void)hipFree(p);
     if (c->pin_th) (void)hipHostFree(c->pin_th);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
@@ -2501,6 +2700,16 @@ int vamp_ctx_set_packing(vamp_ctx* c, int lanes_per_walker) {
     return VAMP_OK;
 }
 
+int vamp_ctx_set_option(vamp_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return fail(VAMP_ERR_ARG, "vamp_ctx_set_option: NULL argument");
+    const std::string key(name);
+    if (key == "map_device") c->opt_map_device = value != 0;
+    else if (key == "resident") c->opt_resident = value != 0;
+    else if (key == "class_streams") c->concurrent_classes = value != 0;
+    else return fail(VAMP_ERR_ARG, "vamp_ctx_set_option: unknown option '" + key + "' (map_device, resident, class_streams)");
+    return VAMP_OK;
+}
+
 int vamp_ctx_synchronize(vamp_ctx* c) {
     if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_synchronize: ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
@@ -2539,6 +2748,7 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         d.D = q * d.K + d.sample_sd;
         d.d_before = r ? R[r - 1].d_before + R[r - 1].D : 0;
         d.tau_off = r ? R[r - 1].tau_off + (long long)R[r - 1].K * R[r - 1].P : 0;
+        d.sim_off = r ? R[r - 1].sim_off + (long long)(R[r - 1].D + 1) * R[r - 1].D : 0;
         const double* xr = x + pix_off[r];
         if (bounds) {
             d.c_lo = bounds[4 * r + 0];
@@ -2791,8 +3001,61 @@ int vamp_map_all(vamp_ctx* c, const double* theta0, const uint8_t* active, int64
     if (c->n_regions == 0) return fail(VAMP_ERR_STATE, "vamp_map_all: call vamp_set_regions first");
     if (c->n_regions > 65535) return fail(VAMP_ERR_ARG, "vamp_map_all: at most 65535 regions per launch");
     if (maxiter < 0 || maxfun < 0 || !(xtol >= 0.0) || !(ftol >= 0.0)) return fail(VAMP_ERR_ARG, "vamp_map_all: bad limits");
-    // the searches themselves: csrc/map_search.hpp (scipy fmin's rules; shared with the host build of this ABI)
     RoctxRange range("vamp_map_all");
+    if (c->opt_map_device) {
+        // every region's whole search in ONE launch per launch class (k_map_search), no per-iteration synchronisation
+        HIP_TRY(hipSetDevice(c->device));
+        const RegionDev& last = c->regions_h.back();
+        const size_t nth = (size_t)(last.d_before + last.D), nsim = (size_t)(last.sim_off + (long long)(last.D + 1) * last.D);
+        const size_t nr = (size_t)c->n_regions;
+        if (c->map_th_cap < nth) {
+            for (void* p : {(void*)c->map_th_d, (void*)c->map_best_d}) if (p) (void)hipFree(p);
+            c->map_th_d = c->map_best_d = nullptr; c->map_th_cap = 0;
+            HIP_TRY(hipMalloc(&c->map_th_d, nth * sizeof(double)));
+            HIP_TRY(hipMalloc(&c->map_best_d, nth * sizeof(double)));
+            c->map_th_cap = nth;
+        }
+        if (c->map_sim_cap < nsim) {
+            if (c->map_sim_d) (void)hipFree(c->map_sim_d);
+            c->map_sim_d = nullptr; c->map_sim_cap = 0;
+            HIP_TRY(hipMalloc(&c->map_sim_d, nsim * sizeof(double)));
+            c->map_sim_cap = nsim;
+        }
+        if (c->map_r_cap < nr) {
+            if (c->map_act_d) (void)hipFree(c->map_act_d);
+            if (c->map_it_d) (void)hipFree(c->map_it_d);
+            c->map_act_d = nullptr; c->map_it_d = nullptr; c->map_r_cap = 0;
+            HIP_TRY(hipMalloc(&c->map_act_d, nr));
+            HIP_TRY(hipMalloc(&c->map_it_d, nr * sizeof(long long)));
+            c->map_r_cap = nr;
+        }
+        HIP_TRY(hipMemcpyAsync(c->map_th_d, theta0, nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (active) HIP_TRY(hipMemcpyAsync(c->map_act_d, active, nr, hipMemcpyHostToDevice, c->stream));
+        const unsigned char* act_d = active ? c->map_act_d : nullptr;
+        for (size_t ci = 0; ci < c->classes.size(); ++ci) {
+            const LaunchClass& cl = c->classes[ci];
+            // the shape vamp_lnprob runs a single point of this class in: the objective has the same bits
+            const int shape = class_shape(c, cl, 1, true);
+            const dim3 grid((unsigned)cl.regions.size()), threads(shape_threads(shape));
+            if (c->f32)
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_map_search<true, M, PK>), grid, threads, 0, c->stream, c->regions_d, c->pix(),
+                                                          (const int*)cl.list_d, c->map_th_d, act_d, (long long)maxiter, (long long)maxfun, xtol, ftol,
+                                                          c->map_sim_d, c->map_best_d, c->map_it_d));
+            else
+                VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_map_search<false, M, PK>), grid, threads, 0, c->stream, c->regions_d, c->pix(),
+                                                          (const int*)cl.list_d, c->map_th_d, act_d, (long long)maxiter, (long long)maxfun, xtol, ftol,
+                                                          c->map_sim_d, c->map_best_d, c->map_it_d));
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpyAsync(theta_best, c->map_best_d, nth * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        std::vector<long long> its(iterations ? nr : 0);
+        if (iterations) HIP_TRY(hipMemcpyAsync(its.data(), c->map_it_d, nr * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (iterations) for (size_t r = 0; r < nr; ++r) iterations[r] = its[r];
+        return lnprob_impl(c, -1, 1, theta_best, lnprob_best, chi2_best);
+    }
+    // the host-driven form (vamp_ctx_set_option "map_device" = 0): csrc/map_search.hpp (scipy fmin's rules; shared with
+    // the host build of this ABI), one launch + one synchronisation per iteration of all regions
     std::vector<int> dims(c->n_regions);
     std::vector<long long> offs(c->n_regions);
     for (int r = 0; r < c->n_regions; ++r) {
@@ -3180,6 +3443,17 @@ int vamp_comm_info(vamp_ctx* c, int* rank, int* world, int* queried) {
     if (rank) *rank = r;
     if (world) *world = w;
     if (queried) *queried = q;
+    return VAMP_OK;
+}
+
+int vamp_comm_library(char* path, int64_t capacity) {
+    if (!path || capacity < 2) return fail(VAMP_ERR_ARG, "vamp_comm_library: no room for a path");
+    RcclApi* api = nullptr;
+    int rc = rccl_api(&api);
+    if (rc) return rc;
+    Dl_info info;
+    const char* name = (dladdr(reinterpret_cast<void*>(api->AllGather), &info) && info.dli_fname) ? info.dli_fname : "";
+    std::snprintf(path, (size_t)capacity, "%s", name);
     return VAMP_OK;
 }
 

@@ -59,6 +59,14 @@ def comm_unique_id(lib=None):
     return buf.raw
 
 
+def comm_library(lib=None):
+    """File name of the library whose ncclAllGather carries the in-library exchange (vamp_comm_library)."""
+    lib = lib if lib is not None else _lib.load()
+    buf = C.create_string_buffer(4096)
+    _lib.check(lib.vamp_comm_library(buf, 4096), lib)
+    return buf.value.decode("utf-8", "replace")
+
+
 def default_split_block(W, world=1):
     """Largest even divisor of W that is <= 1024 and keeps W/block a multiple of ``world``."""
     for b in range(min(W, 1024), 1, -1):
@@ -118,6 +126,10 @@ class HipContext:
 
     def synchronize(self):
         self._check(self._lib.vamp_ctx_synchronize(self._h))
+
+    def set_option(self, name, value):
+        """Run-time switches (vamp_ctx_set_option): "map_device", "resident", "class_streams"."""
+        self._check(self._lib.vamp_ctx_set_option(self._h, name.encode(), int(value)))
 
     # -- multi-GPU (walker sharding) ---------------------------------------------------------
     def comm_init_rank(self, comm_id, rank, world):
