@@ -76,7 +76,7 @@ class OracleContext:
         with np.errstate(all="ignore"):
             return tau, vo.tau2flux(sum(list(tau)))
 
-    def map_all(self, starts, iterlim=1000, tol=1e-3, active=None, xtol=1e-4):
+    def map_all(self, starts, iterlim=1000, tol=1e-3, active=None, xtol=1e-4, maxfun=0):
         """scipy.optimize.fmin on -lnprob (1e300 where it is not finite), region by region: what
         PyMC 2's ``MAP.fit(method='fmin', iterlim, tol)`` runs (fmin(..., maxiter=iterlim, ftol=tol),
         xtol and maxfun at scipy's defaults 1e-4 and 200 N -- from knowledge, pymc absent)."""
@@ -126,6 +126,24 @@ class OracleContext:
             res["chain"] = chains[0] if one else chains
             res["lnprob"] = lchains[0] if one else lchains
         return res
+
+    def run_flat(self, n_steps, thin=1, store_chain=True):
+        """HipContext.run_flat: the kept samples in the library's layout"""
+        res = self.run(n_steps, thin=thin, store_chain=store_chain)
+        nacc = np.concatenate([np.atleast_1d(n) for n in ([res["n_accept"]] if self.n_regions == 1 else res["n_accept"])])
+        if not store_chain:
+            return None, None, nacc, res["seconds"]
+        ch = [res["chain"]] if self.n_regions == 1 else res["chain"]
+        lc = [res["lnprob"]] if self.n_regions == 1 else res["lnprob"]
+        n_keep = ch[0].shape[0]
+        return (np.concatenate([c.reshape(n_keep, -1) for c in ch], axis=1), np.concatenate(lc, axis=1), nacc, res["seconds"])
+
+    def model_all(self, thetas):
+        res = [self.model(t, region=r) for r, t in enumerate(thetas)]
+        return [np.array(list(a)) for a, _ in res], [b for _, b in res]
+
+    def set_option(self, name, value):
+        pass
 
     def get_state(self):
         if self.n_regions == 1:

@@ -132,6 +132,39 @@ def test_find_bic_and_chain_covariance_match_oracle(voigt, n):
     assert abs(g.map.BIC - (kfree * np.log(nu.size) - 2 * g.map.lnL)) < 1e-9
 
 
+@pytest.mark.parametrize("voigt", [False, True])
+def test_find_bic_batched_matches_oracle(voigt):
+    """The batched find_bic (vamp_amd/batched.py: the three repeats of every region as 3 R regions of ONE
+    context, vpfits.py:417-428) on the HIP library and on the oracle-backed context: the same host logic,
+    the same generator and draw keys, independent arithmetic -- oracle sampler, scipy's own fmin.  Three
+    H I regions with different numbers of lines, 20 steps: bic_array / red_chi_array of every region to
+    1e-9, the kept fit objects' chains, MAP values and model flux likewise; every repeat has a chain of its
+    own (its region index keys the draws)."""
+    import vamp_amd
+    from oracle_ctx import OracleContext
+    from vamp_amd.batched import find_bic_batched
+    regions = [_hi_region(i) for i in range(3)]
+    ns = [1, 2, 1]
+    out = {}
+    for name, ctx in (("hip", vamp_amd.HipContext(device=0)), ("oracle", OracleContext())):
+        out[name] = find_bic_batched(ctx, regions, ns, voigt=voigt, nwalkers=32, iterations=20, thin=1, burn=5, seed=17)
+        assert ctx.n_regions == 9 and len(out[name]) == 3
+    for r, (g, o) in enumerate(zip(out["hip"], out["oracle"])):
+        assert len(g.bic_array) == 3 and len(set(g.bic_array)) == 3, g.bic_array       # three different chains
+        assert np.allclose(g.bic_array, o.bic_array, rtol=1e-9, atol=0), (r, g.bic_array, o.bic_array)
+        assert np.allclose(g.red_chi_array, o.red_chi_array, rtol=1e-9, atol=0), (r, g.red_chi_array, o.red_chi_array)
+        fg, fo = g.detach().fit(), o.detach().fit()
+        assert fg._chain_dev.shape == (15, 32, (4 if voigt else 3) * ns[r] + 1)
+        assert np.allclose(fg._chain_dev, fo._chain_dev, rtol=1e-9, atol=1e-12)
+        assert np.isclose(fg.map.BIC, g.bic_array[-1]) and np.isclose(fg.map.lnL, fo.map.lnL, rtol=1e-9)
+        assert np.allclose(fg.total.value, fo.total.value, rtol=1e-9, atol=1e-300)
+        assert fg.mcmc.DIC is None and len(fg.estimated_profiles) == ns[r]
+        st = fg.mcmc.stats()
+        assert np.isclose(st["xexp_0"]["standard deviation"], fo.mcmc.stats()["xexp_0"]["standard deviation"], rtol=1e-7)
+        nu = regions[r][0]
+        assert nu[0] <= fg.estimated_variables[0]["centroid"].value <= nu[-1]
+
+
 def test_region_fit_ladder_matches_oracle(monkeypatch):
     """VPregion.region_fit (vpregion.py:42-91) on the HIP path and on the oracle: the same sequence
     of rungs, the same BIC / reduced chi^2 triples on every rung (1e-9) and the same final n."""

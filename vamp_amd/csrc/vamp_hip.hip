@@ -1491,10 +1491,11 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_lnprob(
 // ~60 000 per q1422 fit).  The workgroup has the shape k_lnprob runs for the region's launch class, so a point's
 // objective has the bits vamp_lnprob gives it; its SLOTS walker slots evaluate the candidates of an iteration
 // together (reflection, expansion and both contractions when SLOTS >= 4 -- the speculative form of the host
-// search -- otherwise reflection first and the one point fmin asks for next).  The simplex lives in global
-// scratch ((D + 1) x D doubles per region, L2-resident), values / order / centroid in LDS; the vertices are never
+// search -- otherwise reflection first and the one point fmin asks for next).  The simplex lives in LDS
+// up to D = 33, else in global scratch ((D + 1) x D doubles per region, L2-resident), values / order / centroid in LDS; the vertices are never
 // moved, `ord` holds their order.  Regions are independent: no inter-workgroup communication.
 constexpr int NM_INIT = 0, NM_CAND = 1, NM_CAND2 = 2, NM_SHRINK = 3;
+constexpr int NM_LDS_DOUBLES = 34 * 33 + 2;      // simplices up to this size live in LDS (9 KB)
 struct MapLds {
     double xbar[DMAX], worst[DMAX];   // centroid of the N best vertices, the worst vertex
     double f[DMAX + 1];               // objective values, ascending
@@ -1531,7 +1532,9 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_map_sea
         if (tid == 0) iterations[region] = 0;
         return;
     }
-    double* __restrict__ sim = scratch + R.sim_off;            // rows of N doubles: the N + 1 vertices
+    // rows of N doubles: the N + 1 vertices -- in LDS up to N = 33 (8 Voigt lines + sd), else in global scratch
+    __shared__ double sim_lds[NM_LDS_DOUBLES];
+    double* sim = (N + 1) * N <= NM_LDS_DOUBLES ? sim_lds : scratch + R.sim_off;
     typename PK::Lds& L = lds[slot];
     // start simplex: the start point and one vertex per coordinate (vamp::nm_start_coordinate)
     for (int e = tid; e < (N + 1) * N; e += NT) {

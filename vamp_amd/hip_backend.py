@@ -377,9 +377,10 @@ class HipContext:
             o += n
         return out
 
-    def run(self, n_steps, thin=1, store_chain=True):
-        """Returns dict(chain, lnprob, n_accept, seconds); chain/lnprob are arrays for a single
-        region ([n_keep, W, D] / [n_keep, W]) or lists of such arrays."""
+    def run_flat(self, n_steps, thin=1, store_chain=True):
+        """n_steps with the kept samples as the library lays them out: chain [n_keep, total_theta] (the regions'
+        [W, D_r] blocks one after the other), lnprob [n_keep, n_regions * W], n_accept [n_regions * W], seconds.
+        (None for chain / lnprob with store_chain=False.)"""
         n_keep = n_steps // thin
         chain = np.empty((n_keep, self.total_theta)) if store_chain else None
         lchain = np.empty((n_keep, self.total_walkers)) if store_chain else None
@@ -387,6 +388,13 @@ class HipContext:
         sec = C.c_double(0.0)
         self._check(self._lib.vamp_sampler_run(self._h, n_steps, thin, _dp(chain), _dp(lchain),
                                               nacc.ctypes.data_as(_lib.c_int64_p), C.byref(sec)))
+        return chain, lchain, nacc, sec.value
+
+    def run(self, n_steps, thin=1, store_chain=True):
+        """Returns dict(chain, lnprob, n_accept, seconds); chain/lnprob are arrays for a single
+        region ([n_keep, W, D] / [n_keep, W]) or lists of such arrays."""
+        chain, lchain, nacc, seconds = self.run_flat(n_steps, thin=thin, store_chain=store_chain)
+        sec = C.c_double(seconds)
         res = {"seconds": sec.value, "n_accept": nacc if self.n_regions == 1 else self._split(nacc, True)}
         if store_chain:
             ch, lc = self._split(chain, False), self._split(lchain, True)

@@ -389,7 +389,8 @@ class VPfit():
     def _ingest_chain(self, chain, lnpc, n_accept, steps, keep, seconds, scored=None, set_values=True):
         """chain [n_keep, W, D] / lnprob [n_keep, W] of THIS fit's region -> traces, acceptance,
         DIC / BPIC, node values.  ``scored`` = (lnprob, sum) of every kept sample and of the mean
-        point when the caller scored them already (batched fits: all regions in one launch)."""
+        point when the caller scored them already (batched fits: all regions in one launch), or
+        "skip": leave DIC / BPIC at None."""
         W = chain.shape[1]
         self._chain_dev, self._lnp_chain = chain, lnpc
         flat_dev = chain.reshape(-1, self._ndim)
@@ -402,6 +403,12 @@ class VPfit():
         mc_.acceptance_fraction = float(np.mean(n_accept)) / max(1, steps)
         mc_.walker_steps_per_second = W * keep / seconds if seconds > 0 else float("nan")
         # information criteria from the chain (every kept sample scored on the device)
+        if isinstance(scored, str) and scored == "skip":      # batched model selection: DIC / BPIC are not computed
+            mc_.DIC = mc_.BPIC = None
+            if set_values:
+                i = np.unravel_index(np.argmax(lnpc), lnpc.shape)
+                self._set_values(chain[i[0], i[1]])
+            return
         mean_theta = flat_dev.mean(0)
         if scored is None:
             ll = self._loglike(flat_dev)
