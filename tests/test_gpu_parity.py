@@ -792,6 +792,81 @@ def test_map_search_on_device_equals_host_driven(hip_ctx, mode, sd):
         hip_ctx.set_option("map_device", 1)
 
 
+def _mixed_short_context(rng, variant, W, with_xl):
+    """regions of a mixed spectrum-like context (every launch class) with W walkers each; variant 0: (amplitude,
+    centroid, L, G), 1: Gaussian components, 2: variant 0 + the free precision sd, 3: (N, b, z)"""
+    C_LIGHT, SIGMA0, LINE, PIX_HZ = 2.98e8, 0.0263, 1215.67, 4.0e10
+    fps = 2.0 * np.sqrt(2.0 * np.log(2.0))
+    shapes = [(30, 1), (44, 2), (51, 4), (160, 3), (23, 1), (90, 6), (300, 5), (36, 2)] + ([(120, 18)] if with_xl else [])
+    xs, fs, ns, Ks, ths, nbz = [], [], [], [], [], []
+    for P, K in shapes:
+        x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+        c = rng.uniform(x[0] * 0.8, x[-1] * 0.8, K)
+        w = rng.uniform(1.5, 0.05 * P + 2.0, K)
+        tau = sum(rng.uniform(0.3, 2.0) * np.exp(-0.5 * ((x - ck) / wk) ** 2) for ck, wk in zip(c, w))
+        th = np.empty((W, K, 4))
+        th[:, :, 0] = rng.uniform(0.2, 1.5, (W, K))
+        th[:, :, 1] = c + rng.normal(0, 1.5, (W, K))
+        th[:, :, 2] = 10.0 ** rng.uniform(-2, 0.5, (W, K))
+        th[:, :, 3] = fps * w * rng.uniform(0.6, 1.6, (W, K))
+        th[: W // 8, 0, 0] = -0.1                                  # a few walkers start outside the prior
+        xs.append(x); fs.append(np.exp(-tau) + rng.normal(0, 0.02, P)); Ks.append(K)
+        ns.append(np.ones(P) if variant == 2 else np.full(P, 0.02))
+        if variant == 1:
+            t = np.stack([th[:, :, 0], th[:, :, 1], th[:, :, 3] / fps], axis=2).reshape(W, 3 * K)
+        elif variant == 2:
+            t = np.hstack([th.reshape(W, 4 * K), rng.uniform(0.01, 0.2, (W, 1))])
+        elif variant == 3:
+            nu_mid = C_LIGHT / (1225.0 * 1e-10)
+            sig_hz = th[:, :, 3] * PIX_HZ / fps
+            t = np.stack([th[:, :, 0] * sig_hz * np.sqrt(2 * np.pi) / SIGMA0, (LINE * 1e-10 * sig_hz * 2.355 / np.sqrt(2)) * 1e-3,
+                          ((C_LIGHT / (nu_mid + PIX_HZ * th[:, :, 1])) / 1e-10 - LINE) / LINE], axis=2).reshape(W, 3 * K)
+            nbz.append([float(10.0 ** rng.uniform(-1, 0.5)), LINE, nu_mid, PIX_HZ])
+        else:
+            t = th.reshape(W, 4 * K)
+        ths.append(np.ascontiguousarray(t))
+    kw = [dict(mode=vo.MODE_VOIGT4), dict(mode=vo.MODE_GAUSS3), dict(mode=vo.MODE_VOIGT4, sample_sd=True), dict(mode=vo.MODE_NBZ3)][variant]
+    if variant == 3:
+        kw["nbz"] = np.array(nbz)
+    return xs, fs, ns, Ks, ths, kw
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("W", [32, 70])
+def test_resident_step_loop_equals_launch_per_half_step(hip_ctx, variant, W):
+    """The device-resident step loop (k_run_resident: one workgroup per region, the whole loop of vpfits.py:361-395 /
+    420-425 in ONE launch per launch class, half-step barrier = __syncthreads, draws one half-step ahead by an extra
+    wavefront) against vamp_sampler_run with one launch per half-step ("resident" = 0): the same chain, log-posterior
+    chain, acceptance counts and final state BIT FOR BIT, on a mixed multi-region context (one- and two-line regions,
+    blends with per-walker tables, a region of 18 lines) for every parameterisation, an ensemble that fills its
+    wavefronts (W = 32) and one that does not (W = 70: 35 movers), thinning, and a second run that continues the
+    first (step counter, draw keys)."""
+    if hip_ctx.packing_request == 256:
+        pytest.skip("workgroup-per-walker shapes are not resident (long regions are not launch-bound)")
+    rng = np.random.default_rng(40 + variant)
+    xs, fs, ns, Ks, ths, kw = _mixed_short_context(rng, variant, W, with_xl=hip_ctx.packing_request not in (16, 65))
+    out = {}
+    try:
+        for resident in (1, 0):
+            hip_ctx.set_option("resident", resident)
+            hip_ctx.set_regions(xs, fs, ns, Ks, **kw)
+            hip_ctx.sampler_init(ths, seed=77, split_block=W if W == 32 else 14)
+            a = hip_ctx.run_flat(7, thin=3)
+            b = hip_ctx.run_flat(4, thin=1)
+            hip_ctx.run(3, store_chain=False)
+            out[resident] = (a, b, hip_ctx.get_state())
+    finally:
+        hip_ctx.set_option("resident", 1)
+    (a1, b1, s1), (a0, b0, s0) = out[1], out[0]
+    for x1, x0 in ((a1, a0), (b1, b0)):
+        assert x1[0].shape == x0[0].shape and x1[0].shape[0] in (2, 4)
+        assert np.array_equal(x1[0], x0[0]) and np.array_equal(x1[1], x0[1]) and np.array_equal(x1[2], x0[2])
+    assert s1[3] == s0[3] == 14
+    for r in range(len(xs)):
+        assert np.array_equal(s1[0][r], s0[0][r]) and np.array_equal(s1[1][r], s0[1][r]) and np.array_equal(s1[2][r], s0[2][r]), r
+    assert a1[2].sum() > 0 and np.isfinite(a1[1]).any()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_random_long_regions_match_oracle(hip_ctx, seed):
     """Seeded random long regions (full tiles + ragged tail, 1-16 lines) with line widths and

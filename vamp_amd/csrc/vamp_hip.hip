@@ -74,7 +74,6 @@ static_assert(KMAX_ALL >= KMAX && KMAX_ALL < 64, "lane k stages line k; one spar
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
 constexpr int DMAX = 4 * KMAX_ALL + 1;
-constexpr long long PACK_MIN_WALKERS = 16384;   // automatic packing: walkers per launch needed to pay off
 // automatic choice of a 4-wave workgroup per walker (shared Taylor tables of the line cores, see
 // LineTables): regions that give every wave >= 2 tiles.  The choice must not depend on the launch
 // size: a shard of an ensemble has to run the same arithmetic as the whole ensemble on one GPU.
@@ -264,9 +263,12 @@ __device__ __forceinline__ const double* dtab_row(const typename PK::Lds& L, int
 }
 
 // barrier over the lanes that stage and sweep one walker together
+// (a split group of ONE wavefront -- the blend shape -- synchronises like any single wavefront: its lanes' LDS
+//  operations execute in program order, so the device-resident step loop can run several such walkers, one per
+//  wavefront, in one workgroup)
 template <class PK>
 __device__ __forceinline__ void group_barrier() {
-    if constexpr (PK::SPLIT) __syncthreads();
+    if constexpr (PK::SPLIT && PK::WPB > 1) __syncthreads();
     else __builtin_amdgcn_wave_barrier();
 }
 using WaveLds = WalkerLds<KMAX_ALL, true>;  // the one-walker-per-wavefront kernels (k_model, k_line_records): = PackXL::Lds
@@ -1272,10 +1274,10 @@ __device__ __forceinline__ double sweep_blend_passes(const RegionDev& R, const t
             const int kk = e / vamp::TAB_NI, i = e % vamp::TAB_NI, k = k0 + kk;
             vamp::taylor_table_row(i, L.line[k].y, L.dtab[k], L.line[k].pole, L.line[k].hy, tab + kk * vamp::TAB_LINE + i * vamp::TAB_NT);
         }
-        __syncthreads();
+        group_barrier<PK>();
         blend_chunk_n<MODE, PK>(R, L, x, lane, 0, tn0, k0, kn, tab, tau0);
         if (tn1 > 0) blend_chunk_n<MODE, PK>(R, L, x, lane, 256, tn1, k0, kn, tab, tau1);
-        __syncthreads();                            // the next pass overwrites the tables
+        group_barrier<PK>();                        // the next pass overwrites the tables
     }
     double chi = 0.0;
 #pragma unroll
@@ -1336,7 +1338,7 @@ __device__ __forceinline__ double sweep_blend32(const RegionDev& R, const typena
         const int k = e / vamp::TAB_NI, i = e % vamp::TAB_NI;
         vamp::taylor_table_row32(i, L.line[k].y, L.dtab[k], L.line[k].pole, L.line[k].hy, tab32 + k * vamp::TAB32_LINE + i * vamp::TAB32_NT);
     }
-    __syncthreads();
+    group_barrier<PK>();
     double chi = 0.0;
     for (int base = 0; base < R.P; base += 256) {
         const int nt = (R.P - base + 63) >> 6;
@@ -1381,7 +1383,7 @@ __device__ __forceinline__ double sweep_pixels(const RegionDev& R, const typenam
             sweep_class<F32, MODE, PK>(Rs, L, Sx, dct, px, lane, lo, lo + ((Rs.P - lo) / TILE) * TILE, TILE, true, chi, tab);
         chi = wave_sum<64>(chi);
         if (lane == 0) red[part] = chi;
-        __syncthreads();
+        group_barrier<PK>();
         double total = 0.0;
 #pragma unroll
         for (int p = 0; p < PK::WPB; ++p) total += red[p];
@@ -1810,6 +1812,9 @@ struct SamplerDev {
     const int* region_list;      // this launch's regions (a launch class of the ctx), or nullptr = all, in order
     double* pack;                // walker-sharded runs: [slot - slot_begin][D + 1] = the mover's row and lnprob
                                  // after the accept step (what the other devices need), else nullptr
+    int wpr;                     // packed shapes, several regions: wavefronts per region = ceil((W/2) / SUBS), so that every
+                                 // wavefront lies inside one region whatever W is (the last one of a region may have idle
+                                 // groups); 0: slots are dealt to wavefronts linearly (one region, or one walker per wavefront)
 };
 
 // The draws of one mover: which walker holds active slot `a_loc` of `region` in this (step, half),
@@ -1865,12 +1870,64 @@ __global__ __launch_bounds__(256) void k_draws(SamplerDev S, unsigned step, int 
     logz[i] = log(d.z);
 }
 
+constexpr int DRAW_INLINE = 0, DRAW_HOST = 1, DRAW_PRE = 2;      // where a mover's draws come from (k_half_step)
+
+// One mover of a half-step: proposal q = c - (c - s) z into the walker's parameter block in LDS, its log-posterior,
+// the accept test and the state update.  `l` = lane inside the walker's group, `part` = the
+// wavefront's index in a split group; pack_slot >= 0: the row this walker ends with also goes to the exchange buffer.
+// Shared by k_half_step (one launch per half-step) and k_run_resident (the step loop inside the kernel): a walker
+// follows the same arithmetic through either.
+template <bool F32, int DRAWS, int MODE, class PK>
+__device__ __forceinline__ void stretch_move(const SamplerDev& S, const RegionDev& R, typename PK::Lds& L, TileScratch& Sx,
+                                             const double* dct, const PixPtrs& px, int l, int part, double* red, double* tab,
+                                             long long ws, long long wc, double z, double logu, double logz, long long pack_slot) {
+#ifdef VAMP_ROWS_CACHED    // timing-only builds: every row read hits a 64-row window (no HBM latency)
+    double* Xs = S.X + R.theta_off + (ws & 63) * R.D;
+    const double* Xc = S.X + R.theta_off + (wc & 63) * R.D;
+    const long long wg = R.walker_off + (ws & 63);
+#else
+    double* Xs = S.X + R.theta_off + ws * R.D;
+    const double* Xc = S.X + R.theta_off + wc * R.D;
+    const long long wg = R.walker_off + ws;
+#endif
+    // the mover's current lnprob is requested together with the two rows: three random reads of a
+    // state far larger than L2, one exposed round trip instead of two (it is needed only for the
+    // accept test, and left there its miss is paid in full by the one or two waves a SIMD holds)
+    double lnp_s = S.lnp[wg];
+    if (!PK::SPLIT || part == 0)
+        for (int d = l; d < R.D; d += PK::LPW) {
+            const double c = Xc[d];
+            L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
+        }
+#if VAMP_EARLY_LNP
+    asm volatile("" : "+v"(lnp_s));                          // keep the read up here
+#endif
+    group_barrier<PK>();
+    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, Sx, dct, px, l, nullptr, part, red, tab);
+    if (PK::SPLIT && part != 0) return;     // the group's first wave carries out the accept step
+    if constexpr (DRAWS != DRAW_PRE) logz = log(z);
+    const double diff = (double)(R.D - 1) * logz + lnp_q - lnp_s;
+    const bool accept = logu < diff;                      // false for NaN
+    if (pack_slot >= 0 && S.pack) {
+        // active-colour exchange: the row this walker ends the half-step with, in slot order
+        double* pk = S.pack + pack_slot * (long long)(R.D + 1);
+        for (int d = l; d < R.D; d += PK::LPW) pk[d] = accept ? L.theta[d] : Xs[d];
+        if (l == 0) pk[R.D] = accept ? lnp_q : lnp_s;
+    }
+    if (accept) {
+        for (int d = l; d < R.D; d += PK::LPW) Xs[d] = L.theta[d];
+        if (l == 0) {
+            S.lnp[wg] = lnp_q;
+            S.n_accept[wg] += 1;
+        }
+    }
+}
+
 // One half-step of the stretch move, one wavefront per active walker.
 //   DRAWS = DRAW_INLINE: Philox in-kernel; DRAW_HOST: every draw supplied by the host for ONE region
 //   (deterministic-parity hook); DRAW_PRE: read from the arrays k_draws filled for this launch.
 // Wavefronts per SIMD are set per shape (Pack::MIN_WAVES): the tile code is latency-bound in places (LDS and
 // scalar-cache round trips); the headline shape measured 4.29 / 3.46 / 3.28 ms at 2 / 3 / 4 of them
-constexpr int DRAW_INLINE = 0, DRAW_HOST = 1, DRAW_PRE = 2;
 template <bool F32, int DRAWS, int MODE, class PK>
 __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_step(SamplerDev S, PixPtrs px, unsigned step, int half, int ext_region,
                                                      long long ext_n, const int* __restrict__ ext_active,
@@ -1890,7 +1947,15 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_st
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
     const long long halfW = S.W >> 1;
     // first walker of this wave (a split workgroup: the one walker all of its waves serve)
-    const long long slot0 = PK::SPLIT ? (long long)blockIdx.x : ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS;
+    long long slot0 = PK::SPLIT ? (long long)blockIdx.x : ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS;
+    if (PK::SUBS > 1 && DRAWS != DRAW_HOST && S.wpr > 0) {
+        // several regions, several walkers per wavefront: wavefront g serves SUBS consecutive movers of region
+        // g / wpr; the groups beyond the region's W/2 movers idle (below: slot0 + sub leaves the region's range)
+        const long long g = (long long)blockIdx.x * PK::WPB + wave;
+        const long long ri = g / S.wpr;
+        slot0 = ri * halfW + (g - ri * S.wpr) * PK::SUBS;
+        if (slot0 + sub >= (ri + 1) * halfW) return;
+    }
     long long slot = slot0 + sub;
     int region;
     long long ws, wc;            // local walker ids (within the region) of mover and partner
@@ -1903,8 +1968,8 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_st
         const long long i = slot;                     // index inside this launch
         slot += S.slot_begin;
         if (slot >= S.slot_end) return;
-        // every walker of a wave lies in one region (the host packs only when W/2 and the shard
-        // boundaries are multiples of SUBS): keep the region description in scalar registers
+        // every walker of a wave lies in one region (one region in all, or wavefronts dealt per region: S.wpr):
+        // keep the region description in scalar registers
         const int ridx = __builtin_amdgcn_readfirstlane((int)((slot0 + S.slot_begin) / halfW));
         region = __builtin_amdgcn_readfirstlane(S.region_list ? S.region_list[ridx] : ridx);
         if constexpr (DRAWS == DRAW_PRE) {
@@ -1916,45 +1981,103 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_st
     }
     const RegionDev R = S.regions[region];
     typename PK::Lds& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
-#ifdef VAMP_ROWS_CACHED    // timing-only builds: every row read hits a 64-row window (no HBM latency)
-    double* Xs = S.X + R.theta_off + (ws & 63) * R.D;
-    const double* Xc = S.X + R.theta_off + (wc & 63) * R.D;
-    const long long wg = R.walker_off + (ws & 63);
-#else
-    double* Xs = S.X + R.theta_off + ws * R.D;
-    const double* Xc = S.X + R.theta_off + wc * R.D;
-    const long long wg = R.walker_off + ws;
-#endif
-    // the mover's current lnprob is requested together with the two rows: three random reads of a
-    // state far larger than L2, one exposed round trip instead of two (it is needed only for the
-    // accept test, and left there its miss is paid in full by the one or two waves a SIMD holds)
-    double lnp_s = S.lnp[wg];
-    if (!PK::SPLIT || wave == 0)
-        for (int d = l; d < R.D; d += PK::LPW) {
-            const double c = Xc[d];
-            L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
+    stretch_move<F32, DRAWS, MODE, PK>(S, R, L, scr[PK::FF ? wave : 0], dct, px, l, wave, red, tabs[PK::SPLIT ? 0 : wave].a, ws, wc, z, logu,
+                                       logz, EXT ? -1ll : slot - S.slot_begin);
+}
+
+// ---- device-resident step loop (rows a8 / a10 in the regime the reference lives in) -----------------------------------
+// The reference's fits are a few thousand iterations of a 4..33-parameter model (vpfits.py:417-428, vpregion.py:42); as
+// ensembles of 32..128 walkers per region a launch per half-step is latency-bound (two launches per step, ~10 us each,
+// most of it dispatch and the wavefront's own critical path).  Regions are independent posteriors, so ONE workgroup per
+// region can run the region's whole step loop: its compute wavefronts take the movers of a half-step in rounds
+// (stretch_move: the arithmetic of k_half_step), the half-step barrier is __syncthreads(), the kept samples are written
+// from the kernel, and an extra wavefront draws -- one mover per lane, the same Philox keys -- the NEXT half-step's draws
+// into an LDS double buffer while the others move.  The chain equals the launch-per-half-step chain bit for bit
+// (tests/test_gpu_parity.py::test_resident_step_loop_equals_launch_per_half_step).  No inter-workgroup communication.
+constexpr int RES_MAX_WAVES = 8;            // compute wavefronts of a resident workgroup (+ the one that draws)
+constexpr int RES_MAX_MOVERS = 128;         // movers per half-step (W / 2) a resident workgroup serves
+constexpr size_t RES_MAX_LDS = 64 * 1024;   // dynamic LDS of one resident workgroup
+struct alignas(16) ResDraws {
+    double z[RES_MAX_MOVERS], logu[RES_MAX_MOVERS], logz[RES_MAX_MOVERS];
+    int ws[RES_MAX_MOVERS], wc[RES_MAX_MOVERS];
+};
+// layout of the workgroup's dynamic LDS for nw compute wavefronts (host and device compute it alike)
+template <bool F32, int MODE, class PK>
+struct ResLayout {
+    static constexpr size_t up(size_t v) { return (v + 15) & ~(size_t)15; }
+    using Tabs = LineTables<table_doubles<F32, MODE, PK>()>;
+    static constexpr size_t dct_bytes = PK::FF ? up(ff_table_doubles<F32>() * sizeof(double)) : 0;
+    static constexpr size_t off_draws = dct_bytes;
+    static constexpr size_t off_red = off_draws + 2 * sizeof(ResDraws);
+    __host__ __device__ static constexpr size_t off_scr(int nw) { return off_red + up((size_t)nw * PARTS * sizeof(double)); }
+    __host__ __device__ static constexpr size_t off_tabs(int nw) { return off_scr(nw) + (PK::FF ? up((size_t)nw * sizeof(TileScratch)) : 0); }
+    __host__ __device__ static constexpr size_t off_lds(int nw) { return off_tabs(nw) + up((size_t)nw * sizeof(Tabs)); }
+    __host__ __device__ static constexpr size_t total(int nw) { return off_lds(nw) + up((size_t)nw * PK::SUBS * sizeof(typename PK::Lds)); }
+};
+template <bool F32, int MODE, class PK>
+__global__ __launch_bounds__(64 * (RES_MAX_WAVES + 1), (min_waves<F32, PK>())) void k_run_resident(
+    SamplerDev S, PixPtrs px, unsigned step0, long long n_steps, int thin, double* __restrict__ chain, double* __restrict__ lchain,
+    long long total_theta, long long total_walkers) {
+    static_assert(!PK::SPLIT || PK::WPB == 1, "a walker's group is one wavefront or a part of one");
+    using LY = ResLayout<F32, MODE, PK>;
+    extern __shared__ __align__(16) unsigned char res_raw[];
+    const int nw = (int)(blockDim.x >> 6) - 1;                   // compute wavefronts; wavefront nw draws
+    double* dct = reinterpret_cast<double*>(res_raw);
+    ResDraws* draws = reinterpret_cast<ResDraws*>(res_raw + LY::off_draws);
+    if constexpr (PK::FF) ff_fill_table<F32>(dct);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane / PK::LPW, l = lane % PK::LPW;
+    const bool drawer = wave == nw;
+    const int region = __builtin_amdgcn_readfirstlane(S.region_list ? S.region_list[blockIdx.x] : (int)blockIdx.x);
+    const RegionDev R = S.regions[region];
+    const int halfW = (int)(S.W >> 1);
+    const int slots = nw * PK::SUBS;
+    const int wv = drawer ? 0 : wave;                             // (the drawing wavefront owns no walker slot)
+    double* red = reinterpret_cast<double*>(res_raw + LY::off_red) + wv * PARTS;
+    TileScratch& Sx = reinterpret_cast<TileScratch*>(res_raw + LY::off_scr(nw))[PK::FF ? wv : 0];
+    double* tab = reinterpret_cast<typename LY::Tabs*>(res_raw + LY::off_tabs(nw))[wv].a;
+    typename PK::Lds& L = reinterpret_cast<typename PK::Lds*>(res_raw + LY::off_lds(nw))[wv * PK::SUBS + sub];
+    // the draws of one half-step: which walker holds each active slot, its stretch factor, partner and log u
+    auto draw_all = [&](unsigned step, int half, ResDraws& D) {
+        for (int a = lane; a < halfW; a += 64) {
+            const MoveDraw d = draw_move(S, step, half, region, a);
+            D.ws[a] = (int)d.ws; D.wc[a] = (int)d.wc; D.z[a] = d.z; D.logu[a] = d.logu; D.logz[a] = log(d.z);
         }
-#if VAMP_EARLY_LNP
-    asm volatile("" : "+v"(lnp_s));                          // keep the read up here
-#endif
-    group_barrier<PK>();
-    const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, scr[PK::FF ? wave : 0], dct, px, l, nullptr, wave, red,
-                                                    tabs[PK::SPLIT ? 0 : wave].a);
-    if (PK::SPLIT && wave != 0) return;     // the group's first wave carries out the accept step
-    if constexpr (DRAWS != DRAW_PRE) logz = log(z);
-    const double diff = (double)(R.D - 1) * logz + lnp_q - lnp_s;
-    const bool accept = logu < diff;                      // false for NaN
-    if (!EXT && S.pack) {
-        // active-colour exchange: the row this walker ends the half-step with, in slot order
-        double* pk = S.pack + (slot - S.slot_begin) * (long long)(R.D + 1);
-        for (int d = l; d < R.D; d += PK::LPW) pk[d] = accept ? L.theta[d] : Xs[d];
-        if (l == 0) pk[R.D] = accept ? lnp_q : lnp_s;
-    }
-    if (accept) {
-        for (int d = l; d < R.D; d += PK::LPW) Xs[d] = L.theta[d];
-        if (l == 0) {
-            S.lnp[wg] = lnp_q;
-            S.n_accept[wg] += 1;
+    };
+    if (drawer) draw_all(step0, 0, draws[0]);
+    __syncthreads();
+    long long kept = 0;
+    for (long long it = 0; it < n_steps; ++it) {
+        const unsigned step = step0 + (unsigned)it;
+        for (int half = 0; half < 2; ++half) {
+            const ResDraws& D = draws[half];
+            if (drawer) {                                          // the next half-step's draws, while the others move
+                if (half == 0) draw_all(step, 1, draws[1]);
+                else if (it + 1 < n_steps) draw_all(step + 1u, 0, draws[0]);
+            } else {
+                for (int a0 = 0; a0 < halfW; a0 += slots) {
+                    const int a = a0 + wave * PK::SUBS + sub;
+                    if (a < halfW)
+                        stretch_move<F32, DRAW_PRE, MODE, PK>(S, R, L, Sx, dct, px, l, 0, red, tab, D.ws[a], D.wc[a], D.z[a], D.logu[a],
+                                                              D.logz[a], -1ll);
+                }
+            }
+            __syncthreads();            // the movers' rows are in place (global, workgroup scope), the next draws are complete
+        }
+        if ((it + 1) % thin == 0 && (chain || lchain)) {
+            if (chain) {
+                const double* __restrict__ src = S.X + R.theta_off;
+                double* __restrict__ dst = chain + kept * total_theta + R.theta_off;
+                for (long long e = tid; e < S.W * R.D; e += blockDim.x) dst[e] = src[e];
+            }
+            if (lchain) {
+                const double* __restrict__ src = S.lnp + R.walker_off;
+                double* __restrict__ dst = lchain + kept * total_walkers + R.walker_off;
+                for (long long e = tid; e < S.W; e += blockDim.x) dst[e] = src[e];
+            }
+            ++kept;
+            __syncthreads();            // (the next half-step moves rows this copy reads)
         }
     }
 }
@@ -2222,15 +2345,15 @@ int ensure_part_events(vamp_ctx* c, int parts) {
     return 0;
 }
 
-// kernel shape of class `cl` for an ensemble of `n_walkers` movers per half-step.  `n_walkers` is the
-// UNSHARDED count (W/2 of a walker-sharded single-region ensemble, whatever this device's share or piece
-// of it), so that a shard runs the shape -- the same bits -- the whole ensemble runs on one device; the
-// packed shapes (several walkers per wavefront) only pay off for ensembles that fill the chip.
+// kernel shape of launch class `cl`: a property of the class alone (never of the ensemble's size, of this device's
+// share or piece of it, or of the entry point), so that a walker's log-posterior has the same bits everywhere.
 int class_shape(const vamp_ctx* c, const LaunchClass& cl, long long n_walkers, bool packable) {
+    (void)n_walkers;
     if (cl.kind == CK_XL) return SH_XL;
     if (cl.kind == CK_MID) return SH_MID;
-    if ((cl.kind == CK_SMALL || cl.kind == CK_SMALL2) && packable && (c->packing == 16 || n_walkers >= PACK_MIN_WALKERS))
-        return cl.kind == CK_SMALL2 ? SH_SMALL2 : SH_SMALL;
+    // (round 4: whatever the ensemble's size -- a 32-walker ladder and a 65 536-walker ensemble of the same region run
+    //  the same arithmetic, and so do vamp_lnprob of one point, the MAP search and the device-resident step loop)
+    if ((cl.kind == CK_SMALL || cl.kind == CK_SMALL2) && packable) return cl.kind == CK_SMALL2 ? SH_SMALL2 : SH_SMALL;
     const bool split = cl.kind == CK_WIDE && (c->packing == 256 || (c->packing == 0 && c->min_tiles >= 2 * PARTS));
     if (split) return c->full_tiles ? SH_SPLIT_FULL : SH_SPLIT;
     return c->full_tiles ? SH_WIDE_FULL : SH_WIDE;
@@ -2267,6 +2390,7 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     S.n_accept = c->nacc_d;
     S.region_list = nullptr;
     S.slot_begin = S.slot_end = 0;
+    S.wpr = 0;
     S.pack = (!ext && c->send_d) ? c->send_d + (long long)part * c->part_slots * (c->regions_h[0].D + 1) : nullptr;
     if (!ext && c->send_d) {
         c->part_step[part] = (unsigned)c->step;
@@ -2295,9 +2419,9 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     const long long halfW = c->W / 2;
     const int* ni = nullptr;
     const double* nd = nullptr;
-    // <16 lanes, 8 lines> packing needs every wave inside one region and one shard
-    const int subs = std::max(PackSmall::SUBS, PackSmall2::SUBS);
-    const bool packable = !ext && halfW % subs == 0 && (c->split_block / 2) % subs == 0;
+    // several walkers per wavefront need every wavefront inside one region: trivially so with one region, else the
+    // wavefronts are dealt per region (SamplerDev::wpr); host-supplied draws run one walker per wavefront
+    const bool packable = !ext;
     const size_t ncls = c->classes.size();
     const bool fork = !ext && ncls > 1 && c->concurrent_classes;
     if (fork) {
@@ -2339,9 +2463,15 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
             HIP_TRY(hipStreamWaitEvent(st, c->ev_fork, 0));
         }
         S.region_list = cl.list_d;
-        // (a shard or a piece of a single-region ensemble takes the shape of the WHOLE ensemble)
-        const int shape = class_shape(c, cl, (!ext && c->n_regions == 1) ? halfW : n, packable);
-        const unsigned grid = (unsigned)((n + shape_walkers_per_block(shape) - 1) / shape_walkers_per_block(shape));
+        const int shape = class_shape(c, cl, n, packable);
+        unsigned grid = (unsigned)((n + shape_walkers_per_block(shape) - 1) / shape_walkers_per_block(shape));
+        S.wpr = 0;
+        if (!ext && c->n_regions > 1 && (shape == SH_SMALL || shape == SH_SMALL2)) {
+            const long long subs = shape == SH_SMALL ? PackSmall::SUBS : PackSmall2::SUBS;
+            const long long wpb = shape == SH_SMALL ? PackSmall::WPB : PackSmall2::WPB;
+            S.wpr = (int)((halfW + subs - 1) / subs);
+            grid = (unsigned)(((long long)cl.regions.size() * S.wpr + wpb - 1) / wpb);
+        }
         const dim3 threads(shape_threads(shape));
         if (ext) {
             if (c->f32)
@@ -2382,6 +2512,113 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
         }
     }
     if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
+    return 0;
+}
+
+// ---- the device-resident step loop (k_run_resident): eligibility and launch ----------------------------------------
+// compute wavefronts of a resident workgroup of shape PK for `movers` movers per half-step, or 0: does not fit
+template <bool F32, int MODE, class PK>
+int resident_waves(long long movers) {
+    if constexpr (PK::SPLIT && PK::WPB > 1) return 0;
+    else {
+        int nw = (int)std::min<long long>(RES_MAX_WAVES, (movers + PK::SUBS - 1) / PK::SUBS);
+        while (nw > 0 && ResLayout<F32, MODE, PK>::total(nw) > RES_MAX_LDS) --nw;
+        return nw;
+    }
+}
+template <bool F32, int MODE, class PK>
+void launch_resident(dim3 grid, dim3 threads, int nw, hipStream_t st, const SamplerDev& S, const PixPtrs& px, unsigned step0, long long n_steps,
+                     int thin, double* chain_dev, double* lchain_dev, long long total_theta, long long total_walkers) {
+    if constexpr (!(PK::SPLIT && PK::WPB > 1)) {    // (resident_waves is 0 for the workgroup-per-walker shapes: never launched)
+        using LY = ResLayout<F32, MODE, PK>;
+        const size_t lds = LY::total(nw);
+        hipLaunchKernelGGL((k_run_resident<F32, MODE, PK>), grid, threads, lds, st, S, px, step0, n_steps, thin, chain_dev, lchain_dev,
+                           total_theta, total_walkers);
+    }
+}
+int resident_waves_for(const vamp_ctx* c, int shape, long long movers) {
+    int nw = 0;
+    if (c->f32) VAMP_FOR_MODE_PK(c->mode, shape, nw = resident_waves<true, M, PK>(movers));
+    else VAMP_FOR_MODE_PK(c->mode, shape, nw = resident_waves<false, M, PK>(movers));
+    return nw;
+}
+// every launch class of the context can run its regions' step loops inside one launch each
+bool resident_eligible(const vamp_ctx* c) {
+    if (!c->opt_resident || !c->sampler_ready) return false;
+    if (c->shard_world != 1 || c->shard_parts != 1 || c->comm || c->send_d) return false;     // walker-sharded: the exchange is per half-step
+    const long long halfW = c->W / 2;
+    if (halfW > RES_MAX_MOVERS) return false;
+    for (const LaunchClass& cl : c->classes)
+        if (resident_waves_for(c, class_shape(c, cl, halfW, true), halfW) <= 0) return false;
+    return true;
+}
+// n_steps of every region, one launch per launch class (the classes on forked streams, as in launch_half)
+int run_resident(vamp_ctx* c, long long n_steps, int thin, double* chain_dev, double* lchain_dev) {
+    SamplerDev S;
+    std::memset(&S, 0, sizeof(S));
+    S.regions = c->regions_d;
+    S.n_regions = c->n_regions;
+    S.W = c->W;
+    S.split_block = c->split_block;
+    S.a = c->a;
+    S.seed = c->seed;
+    S.X = c->X_d;
+    S.lnp = c->lnp_d;
+    S.n_accept = c->nacc_d;
+    const long long halfW = c->W / 2;
+    const size_t ncls = c->classes.size();
+    const bool fork = ncls > 1 && c->concurrent_classes;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        if (c->ev_used == c->ev.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            c->ev.emplace_back(a, b);
+        }
+        e0 = c->ev[c->ev_used].first;
+        e1 = c->ev[c->ev_used].second;
+        c->ev_used++;
+        HIP_TRY(hipEventRecord(e0, c->stream));
+    }
+    if (fork) {
+        while (c->cls_stream.size() < ncls - 1) {
+            hipStream_t st;
+            hipEvent_t ev;
+            HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->cls_stream.push_back(st);
+            c->ev_join.push_back(ev);
+        }
+        if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    }
+    const PixPtrs px = c->pix();
+    for (size_t ci = 0; ci < ncls; ++ci) {
+        const LaunchClass& cl = c->classes[ci];
+        hipStream_t st = c->stream;
+        if (fork && ci > 0) {
+            st = c->cls_stream[ci - 1];
+            HIP_TRY(hipStreamWaitEvent(st, c->ev_fork, 0));
+        }
+        S.region_list = cl.list_d;
+        const int shape = class_shape(c, cl, halfW, true);
+        const int nw = resident_waves_for(c, shape, halfW);
+        const dim3 grid((unsigned)cl.regions.size()), threads(64u * (unsigned)(nw + 1));
+        if (c->f32)
+            VAMP_FOR_MODE_PK(c->mode, shape, (launch_resident<true, M, PK>(grid, threads, nw, st, S, px, (unsigned)c->step, n_steps, thin, chain_dev,
+                                                                          lchain_dev, c->total_theta, c->total_walkers)));
+        else
+            VAMP_FOR_MODE_PK(c->mode, shape, (launch_resident<false, M, PK>(grid, threads, nw, st, S, px, (unsigned)c->step, n_steps, thin, chain_dev,
+                                                                           lchain_dev, c->total_theta, c->total_walkers)));
+        HIP_TRY(hipGetLastError());
+        if (fork && ci > 0) {
+            HIP_TRY(hipEventRecord(c->ev_join[ci - 1], st));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join[ci - 1], 0));
+        }
+    }
+    if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
+    c->step += n_steps;
     return 0;
 }
 
@@ -3344,6 +3581,14 @@ int vamp_sampler_run_dev(vamp_ctx* c, int64_t n_steps, int thin, double* chain_d
     HIP_TRY(hipStreamSynchronize(c->stream));
     const auto t0 = std::chrono::steady_clock::now();
     long long kept = 0;
+    if (n_steps > 0 && resident_eligible(c)) {
+        // small ensembles: every region's whole step loop in ONE launch per launch class (k_run_resident)
+        int rc = run_resident(c, n_steps, thin, n_keep ? chain_dev : nullptr, n_keep ? lnprob_chain_dev : nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return VAMP_OK;
+    }
     for (long long it = 0; it < n_steps; ++it) {
         for (int half = 0; half < 2; ++half) {
             int rc = half_step_all(c, half);
