@@ -73,9 +73,11 @@ int vamp_ctx_synchronize(vamp_ctx* ctx);
  *   "map_device"     1: vamp_map_all runs every region's whole Nelder-Mead search in one launch (one workgroup
  *                    per region); 0: the host drives the same search, one launch + one synchronisation per
  *                    iteration of all regions.  Same rules, same arithmetic: identical results.
- *   "resident"       1: vamp_sampler_run(_dev) steps small ensembles (regions whose movers of a half-step fit one
- *                    workgroup) with the whole step loop inside ONE launch per launch class; 0: always one launch
- *                    per half-step.  Same draws, same kernels' arithmetic: identical chains.
+ *   "resident"       1: vamp_sampler_run(_dev) steps small ensembles with the whole step loop inside ONE launch per
+ *                    launch class (one workgroup per region) where that pays: contexts of at most 256 short regions
+ *                    (<= 8 components, the packed shapes) whose movers of a half-step (W / 2 <= 128) fit one round of
+ *                    the workgroup; 2: wherever the kernel can run (every shape but the workgroup-per-walker one);
+ *                    0: always one launch per half-step.  Same draws, same arithmetic: identical chains.
  *   "class_streams"  1: the launch classes of a half-step run concurrently on forked streams; 0: one after the
  *                    other (what the per-class profiles use).  Also set by VAMP_CLASS_STREAMS in the environment. */
 int vamp_ctx_set_option(vamp_ctx* ctx, const char* name, int64_t value);

@@ -848,7 +848,7 @@ def test_resident_step_loop_equals_launch_per_half_step(hip_ctx, variant, W):
     out = {}
     try:
         for resident in (1, 0):
-            hip_ctx.set_option("resident", resident)
+            hip_ctx.set_option("resident", 2 * resident)      # 2: every context the kernel can run, not only where it pays
             hip_ctx.set_regions(xs, fs, ns, Ks, **kw)
             hip_ctx.sampler_init(ths, seed=77, split_block=W if W == 32 else 14)
             a = hip_ctx.run_flat(7, thin=3)

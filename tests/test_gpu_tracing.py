@@ -24,7 +24,10 @@ ctx.set_regions(x, flux, np.full(64, 0.02), 1, mode=vamp_amd.MODE_GAUSS3)
 rng = np.random.default_rng(1)
 X0 = np.stack([rng.uniform(0.8, 1.6, 32), rng.uniform(-2, 2, 32), rng.uniform(3, 5, 32)], 1)
 ctx.sampler_init(X0, seed=1)
+ctx.set_option("resident", 0)     # one launch per half-step: a range per half-step
 ctx.run(5)
+ctx.set_option("resident", 1)     # a 32-walker region is taken by the device-resident loop: one range, one launch
+ctx.run(7)
 best, lnp, chi, its = ctx.map_all([X0[0]], iterlim=20)
 ctx.close()
 print("done")
@@ -46,8 +49,10 @@ def test_roctx_ranges_show_in_a_marker_trace(tmp_path):
     files = glob.glob(str(out / "**" / "*marker_api_trace.csv"), recursive=True)
     assert files, "no marker trace written"
     names = [row["Function"] for f in files for row in csv.DictReader(open(f))]
-    assert names.count("vamp_sampler_init") == 1 and names.count("vamp_sampler_run") == 1
+    assert names.count("vamp_sampler_init") == 1 and names.count("vamp_sampler_run") == 2
+    assert names.count("vamp resident step loop") == 1
     assert names.count("vamp half-step 0 (red moves)") == 5 and names.count("vamp half-step 1 (blue moves)") == 5
     assert names.count("vamp_map_all") == 1
     kernels = [row["Kernel_Name"] for f in glob.glob(str(out / "**" / "*kernel_trace.csv"), recursive=True) for row in csv.DictReader(open(f))]
-    assert sum("k_half_step" in k for k in kernels) == 10
+    assert sum("k_half_step" in k for k in kernels) == 10 and sum("k_run_resident" in k for k in kernels) == 1
+    assert sum("k_map_search" in k for k in kernels) == 1          # the whole MAP search: one launch

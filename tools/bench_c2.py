@@ -18,11 +18,13 @@ ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--comp", type=int, default=4)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("--packing", type=int, default=0)
+ap.add_argument("--region", type=int, default=0, help="which H I region of the simba spectrum (0: 44 px)")
+ap.add_argument("--resident", type=int, default=1, help="0: one launch per half-step; 1: the device-resident loop where the library's policy takes it; 2: wherever it can run")
 a = ap.parse_args()
 import vamp_amd
 from vamp_amd.physics import Wave2freq
 g = np.load(os.path.join(ROOT, "tests", "golden", "simba_spectra.npz"))
-s, e = g["H1215_region_pixels"][0]
+s, e = g["H1215_region_pixels"][a.region]
 nu = np.flip(Wave2freq(g["H1215_wavelength"][s:e]), 0)
 flux, noise = np.flip(g["H1215_flux"][s:e], 0), np.flip(g["H1215_noise"][s:e], 0)
 x = (nu - 0.5 * (nu[0] + nu[-1])) / ((nu[-1] - nu[0]) / (nu.size - 1))
@@ -36,6 +38,7 @@ for k in range(K):
     th[:, 4 * k + 3] = rng.uniform(2, 15, W)
 ctx = vamp_amd.HipContext(device=0, dtype=vamp_amd.F64 if a.dtype == "f64" else vamp_amd.F32)
 ctx.set_packing(a.packing)
+ctx.set_option("resident", a.resident)
 ctx.set_regions(x, flux, noise, K, mode=vamp_amd.MODE_VOIGT4)
 ctx.sampler_init(th, seed=5)
 ctx.run(50, store_chain=False)
@@ -48,4 +51,5 @@ ms, n = ctx.kernel_timing(False)
 print(json.dumps({"config": f"simba H I region, P={x.size}, K={K}, W={W}, {a.dtype}", "walker_steps_per_s": W * a.steps / dt,
                   "us_per_half_step_wall": dt / a.steps / 2 * 1e6, "us_per_half_step_kernel": ms / max(1, n) * 1e3,
                   "faddeeva_gevals_per_s": W * a.steps * x.size * K / dt / 1e9,
-                  "acceptance_fraction": float(res["n_accept"].mean()) / (a.steps + 50), "packing": a.packing}))
+                  "acceptance_fraction": float(res["n_accept"].mean()) / (a.steps + 50), "packing": a.packing,
+                  "resident_requested": bool(a.resident), "launches_timed": n}))

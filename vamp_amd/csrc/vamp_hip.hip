@@ -137,6 +137,21 @@ struct LineRec {           // per (walker, component), lives in LDS
 #endif
 constexpr int PARTS = VAMP_PARTS;
 template <int KCAP, bool OWN_DTAB> struct WalkerLds;
+// Timing-only builds (-DVAMP_STAMPS, tools/stamps.py): the first lane of workgroup 0 records (tag, shader clock) pairs
+// along one walker's path through a half-step -- where a latency-bound wavefront's time goes
+#ifdef VAMP_STAMPS
+__device__ unsigned long long g_stamps[2 * 8192];
+__device__ unsigned int g_stamp_n;
+#define VAMP_STAMP(tag)                                                                          \
+    do {                                                                                         \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                               \
+            const unsigned int n_ = g_stamp_n;                                                   \
+            if (n_ < 8192) { g_stamps[2 * n_] = (tag); g_stamps[2 * n_ + 1] = __builtin_amdgcn_s_memtime(); g_stamp_n = n_ + 1; } \
+        }                                                                                        \
+    } while (0)
+#else
+#define VAMP_STAMP(tag) do {} while (0)
+#endif
 #ifndef VAMP_SPLIT_WAVES
 #define VAMP_SPLIT_WAVES 4
 #endif
@@ -1428,6 +1443,7 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, typename PK::L
                                               const PixPtrs& px, int lane, double* chi_out, int part, double* red, double* tab) {
     const double lp = stage_lines<MODE, PK, use_tables<F32, MODE, PK>() && PK::LINES_PER_PASS == 0, use_tables32<F32, MODE, PK>(),
                                   use_blend32<F32, MODE, PK>()>(R, L, lane, F32, part, tab);
+    VAMP_STAMP(3);
     if (!(lp > NEG_INF) || lp != lp) {       // outside the prior (or NaN): skip the sweep
         if (chi_out) *chi_out = __builtin_nan("");
         return NEG_INF;
@@ -1437,6 +1453,7 @@ __device__ __forceinline__ double wave_lnprob(const RegionDev& R, typename PK::L
 #else
     const double ssum = sweep_pixels<F32, MODE, PK>(R, L, Sx, dct, px, lane, part, red, tab);
 #endif
+    VAMP_STAMP(4);
     if (chi_out) *chi_out = ssum;
     double v = lp + loglike_from_sum(R, L, ssum);
     if (v != v) v = NEG_INF;                 // NaN -> -inf (emcee convention)
@@ -1893,17 +1910,20 @@ __device__ __forceinline__ void stretch_move(const SamplerDev& S, const RegionDe
     // the mover's current lnprob is requested together with the two rows: three random reads of a
     // state far larger than L2, one exposed round trip instead of two (it is needed only for the
     // accept test, and left there its miss is paid in full by the one or two waves a SIMD holds)
+    VAMP_STAMP(1);
     double lnp_s = S.lnp[wg];
     if (!PK::SPLIT || part == 0)
         for (int d = l; d < R.D; d += PK::LPW) {
             const double c = Xc[d];
             L.theta[d] = c - (c - Xs[d]) * z;                 // q = c - (c - s) z
         }
+    VAMP_STAMP(2);
 #if VAMP_EARLY_LNP
     asm volatile("" : "+v"(lnp_s));                          // keep the read up here
 #endif
     group_barrier<PK>();
     const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, Sx, dct, px, l, nullptr, part, red, tab);
+    VAMP_STAMP(5);
     if (PK::SPLIT && part != 0) return;     // the group's first wave carries out the accept step
     if constexpr (DRAWS != DRAW_PRE) logz = log(z);
     const double diff = (double)(R.D - 1) * logz + lnp_q - lnp_s;
@@ -1921,6 +1941,7 @@ __device__ __forceinline__ void stretch_move(const SamplerDev& S, const RegionDe
             S.n_accept[wg] += 1;
         }
     }
+    VAMP_STAMP(6);
 }
 
 // One half-step of the stretch move, one wavefront per active walker.
@@ -1981,6 +2002,7 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_st
     }
     const RegionDev R = S.regions[region];
     typename PK::Lds& L = lds[PK::SPLIT ? 0 : wave * PK::SUBS + sub];
+    VAMP_STAMP(0);
     stretch_move<F32, DRAWS, MODE, PK>(S, R, L, scr[PK::FF ? wave : 0], dct, px, l, wave, red, tabs[PK::SPLIT ? 0 : wave].a, ws, wc, z, logu,
                                        logz, EXT ? -1ll : slot - S.slot_begin);
 }
@@ -1996,7 +2018,8 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_st
 // (tests/test_gpu_parity.py::test_resident_step_loop_equals_launch_per_half_step).  No inter-workgroup communication.
 constexpr int RES_MAX_WAVES = 8;            // compute wavefronts of a resident workgroup (+ the one that draws)
 constexpr int RES_MAX_MOVERS = 128;         // movers per half-step (W / 2) a resident workgroup serves
-constexpr size_t RES_MAX_LDS = 64 * 1024;   // dynamic LDS of one resident workgroup
+constexpr size_t RES_MAX_LDS = 150 * 1024;  // dynamic LDS of one resident workgroup (a workgroup may take all 160 KB of its CU)
+constexpr int RES_MAX_REGIONS = 256;        // automatic policy: at most one resident workgroup per compute unit
 struct alignas(16) ResDraws {
     double z[RES_MAX_MOVERS], logu[RES_MAX_MOVERS], logz[RES_MAX_MOVERS];
     int ws[RES_MAX_MOVERS], wc[RES_MAX_MOVERS];
@@ -2052,6 +2075,7 @@ __global__ __launch_bounds__(64 * (RES_MAX_WAVES + 1), (min_waves<F32, PK>())) v
         const unsigned step = step0 + (unsigned)it;
         for (int half = 0; half < 2; ++half) {
             const ResDraws& D = draws[half];
+            VAMP_STAMP(0);
             if (drawer) {                                          // the next half-step's draws, while the others move
                 if (half == 0) draw_all(step, 1, draws[1]);
                 else if (it + 1 < n_steps) draw_all(step + 1u, 0, draws[0]);
@@ -2063,7 +2087,9 @@ __global__ __launch_bounds__(64 * (RES_MAX_WAVES + 1), (min_waves<F32, PK>())) v
                                                               D.logz[a], -1ll);
                 }
             }
+            VAMP_STAMP(7);
             __syncthreads();            // the movers' rows are in place (global, workgroup scope), the next draws are complete
+            VAMP_STAMP(8);
         }
         if ((it + 1) % thin == 0 && (chain || lchain)) {
             if (chain) {
@@ -2156,6 +2182,8 @@ inline long long shape_walkers_per_block(int sh) {
     return sh == SH_SMALL ? PackSmall::WALKERS_PER_BLOCK : sh == SH_SMALL2 ? PackSmall2::WALKERS_PER_BLOCK : sh == SH_MID ? PackMid::WALKERS_PER_BLOCK
            : sh == SH_XL ? PackXL::WALKERS_PER_BLOCK : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? 1 : PackWide::WALKERS_PER_BLOCK;
 }
+inline long long shape_waves(int sh) { return (long long)(sh == SH_SMALL ? PackSmall::WPB : sh == SH_SMALL2 ? PackSmall2::WPB : sh == SH_MID ? PackMid::WPB
+                                                           : sh == SH_XL ? PackXL::WPB : PackWide::WPB); }
 inline unsigned shape_threads(int sh) {
     return sh == SH_SMALL ? PackSmall::THREADS : sh == SH_SMALL2 ? PackSmall2::THREADS : sh == SH_MID ? PackMid::THREADS
            : sh == SH_XL ? PackXL::THREADS : (sh == SH_SPLIT || sh == SH_SPLIT_FULL) ? PackSplit::THREADS : PackWide::THREADS;
@@ -2246,7 +2274,8 @@ struct vamp_ctx {
     size_t map_th_cap = 0, map_sim_cap = 0, map_r_cap = 0;
     // run-time options (vamp_ctx_set_option)
     int opt_map_device = 1;          // 1: vamp_map_all runs k_map_search; 0: the host-driven search, one launch per iteration
-    int opt_resident = 1;            // 1: small ensembles are stepped by the device-resident loop where it applies; 0: never
+    int opt_resident = 1;            // 1: small ensembles are stepped by the device-resident loop where it pays (resident_eligible);
+                                     // 0: never; 2: wherever the kernel can run
     // scratch for the ext hook
     int *ext_act_d = nullptr, *ext_par_d = nullptr;
     double *ext_z_d = nullptr, *ext_lu_d = nullptr;
@@ -2352,7 +2381,9 @@ int class_shape(const vamp_ctx* c, const LaunchClass& cl, long long n_walkers, b
     if (cl.kind == CK_XL) return SH_XL;
     if (cl.kind == CK_MID) return SH_MID;
     // (round 4: whatever the ensemble's size -- a 32-walker ladder and a 65 536-walker ensemble of the same region run
-    //  the same arithmetic, and so do vamp_lnprob of one point, the MAP search and the device-resident step loop)
+    //  the same arithmetic, and so do vamp_lnprob of one point, the MAP search and the device-resident step loop.
+    //  Sixteen lanes per walker for the one- and two-line regions of small launches was measured and dropped:
+    //  profiles/r04_c_small_ensembles.txt)
     if ((cl.kind == CK_SMALL || cl.kind == CK_SMALL2) && packable) return cl.kind == CK_SMALL2 ? SH_SMALL2 : SH_SMALL;
     const bool split = cl.kind == CK_WIDE && (c->packing == 256 || (c->packing == 0 && c->min_tiles >= 2 * PARTS));
     if (split) return c->full_tiles ? SH_SPLIT_FULL : SH_SPLIT;
@@ -2463,7 +2494,8 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
             HIP_TRY(hipStreamWaitEvent(st, c->ev_fork, 0));
         }
         S.region_list = cl.list_d;
-        const int shape = class_shape(c, cl, n, packable);
+        // (a shard or a piece of a single-region ensemble takes the shape of the WHOLE ensemble)
+        const int shape = class_shape(c, cl, (!ext && c->n_regions == 1) ? halfW : n, packable);
         unsigned grid = (unsigned)((n + shape_walkers_per_block(shape) - 1) / shape_walkers_per_block(shape));
         S.wpr = 0;
         if (!ext && c->n_regions > 1 && (shape == SH_SMALL || shape == SH_SMALL2)) {
@@ -2532,6 +2564,8 @@ void launch_resident(dim3 grid, dim3 threads, int nw, hipStream_t st, const Samp
     if constexpr (!(PK::SPLIT && PK::WPB > 1)) {    // (resident_waves is 0 for the workgroup-per-walker shapes: never launched)
         using LY = ResLayout<F32, MODE, PK>;
         const size_t lds = LY::total(nw);
+        if (lds > 48 * 1024)        // beyond the default dynamic allocation: the kernel is told once per process
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_run_resident<F32, MODE, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_MAX_LDS);
         hipLaunchKernelGGL((k_run_resident<F32, MODE, PK>), grid, threads, lds, st, S, px, step0, n_steps, thin, chain_dev, lchain_dev,
                            total_theta, total_walkers);
     }
@@ -2542,14 +2576,30 @@ int resident_waves_for(const vamp_ctx* c, int shape, long long movers) {
     else VAMP_FOR_MODE_PK(c->mode, shape, nw = resident_waves<false, M, PK>(movers));
     return nw;
 }
+// movers of one half-step launch of class `cl` on the launch-per-half-step path (what decides its shape)
+long long class_movers(const vamp_ctx* c, const LaunchClass& cl) {
+    return c->n_regions == 1 ? c->W / 2 : (long long)cl.regions.size() * (c->W / 2);
+}
 // every launch class of the context can run its regions' step loops inside one launch each
+// Policy (opt_resident = 1; measured, profiles/r04_c_small_ensembles.txt).  A resident workgroup removes the dispatch
+// gap of a launch per half-step (~5 us of ~16) but serialises its region on ONE compute unit, so it pays only where
+// the launch path cannot use the chip anyway: at most one workgroup per compute unit (<= RES_MAX_REGIONS regions),
+// every mover of a half-step in ONE round of the workgroup's wavefronts, and only the packed short-region classes
+// (a blend or a region of 17+ lines takes a whole wavefront per walker: eight movers per round).  opt_resident = 2
+// (tests, A/B) takes every context the kernel can run.
 bool resident_eligible(const vamp_ctx* c) {
     if (!c->opt_resident || !c->sampler_ready) return false;
     if (c->shard_world != 1 || c->shard_parts != 1 || c->comm || c->send_d) return false;     // walker-sharded: the exchange is per half-step
     const long long halfW = c->W / 2;
     if (halfW > RES_MAX_MOVERS) return false;
-    for (const LaunchClass& cl : c->classes)
-        if (resident_waves_for(c, class_shape(c, cl, halfW, true), halfW) <= 0) return false;
+    if (c->opt_resident == 1 && c->n_regions > RES_MAX_REGIONS) return false;
+    for (const LaunchClass& cl : c->classes) {
+        const int shape = class_shape(c, cl, class_movers(c, cl), true);
+        const int nw = resident_waves_for(c, shape, halfW);
+        if (nw <= 0) return false;
+        if (c->opt_resident == 1 && (!(cl.kind == CK_SMALL || cl.kind == CK_SMALL2) || nw * shape_walkers_per_block(shape) / shape_waves(shape) < halfW))
+            return false;
+    }
     return true;
 }
 // n_steps of every region, one launch per launch class (the classes on forked streams, as in launch_half)
@@ -2602,7 +2652,7 @@ int run_resident(vamp_ctx* c, long long n_steps, int thin, double* chain_dev, do
             HIP_TRY(hipStreamWaitEvent(st, c->ev_fork, 0));
         }
         S.region_list = cl.list_d;
-        const int shape = class_shape(c, cl, halfW, true);
+        const int shape = class_shape(c, cl, class_movers(c, cl), true);     // the shape launch_half runs this class in
         const int nw = resident_waves_for(c, shape, halfW);
         const dim3 grid((unsigned)cl.regions.size()), threads(64u * (unsigned)(nw + 1));
         if (c->f32)
@@ -2883,6 +2933,8 @@ int vamp_ctx_create(vamp_ctx** out, int device, int dtype, int wofz_kind) {
     }
     c->stream = c->own_stream;
     if (const char* e = getenv("VAMP_CLASS_STREAMS")) c->concurrent_classes = std::atoi(e) != 0;
+    if (const char* e = getenv("VAMP_RESIDENT")) c->opt_resident = std::max(0, std::min(2, std::atoi(e)));          // (A/B knobs of tools/ and profiles/;
+    if (const char* e = getenv("VAMP_MAP_DEVICE")) c->opt_map_device = std::atoi(e) != 0;      //  vamp_ctx_set_option overrides them)
     *out = c;
     return VAMP_OK;
 }
@@ -2944,7 +2996,7 @@ int vamp_ctx_set_option(vamp_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return fail(VAMP_ERR_ARG, "vamp_ctx_set_option: NULL argument");
     const std::string key(name);
     if (key == "map_device") c->opt_map_device = value != 0;
-    else if (key == "resident") c->opt_resident = value != 0;
+    else if (key == "resident") c->opt_resident = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (key == "class_streams") c->concurrent_classes = value != 0;
     else return fail(VAMP_ERR_ARG, "vamp_ctx_set_option: unknown option '" + key + "' (map_device, resident, class_streams)");
     return VAMP_OK;
@@ -3583,6 +3635,7 @@ int vamp_sampler_run_dev(vamp_ctx* c, int64_t n_steps, int thin, double* chain_d
     long long kept = 0;
     if (n_steps > 0 && resident_eligible(c)) {
         // small ensembles: every region's whole step loop in ONE launch per launch class (k_run_resident)
+        RoctxRange res_range("vamp resident step loop");
         int rc = run_resident(c, n_steps, thin, n_keep ? chain_dev : nullptr, n_keep ? lnprob_chain_dev : nullptr);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -3773,6 +3826,19 @@ int vamp_exchange_timing(vamp_ctx* c, double* total_ms, int64_t* exchanges) {
     c->xtiming_n = 0;
     return VAMP_OK;
 }
+
+#ifdef VAMP_STAMPS
+// timing-only builds: copy out and reset the (tag, clock) stamps; returns their number
+int vamp_debug_stamps(unsigned long long* out, int cap) {
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_stamp_n), sizeof(n)) != hipSuccess) return -1;
+    if ((int)n > cap) n = (unsigned)cap;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 2 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    const unsigned int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif
 
 int vamp_kernel_timing(vamp_ctx* c, int enable, double* total_ms, int64_t* launches) {
     if (!c) return fail(VAMP_ERR_ARG, "vamp_kernel_timing: ctx is NULL");
