@@ -357,8 +357,9 @@ def main():
     ap.add_argument("--width-scale", type=float, default=1.0, help="multiply the true line widths (G and L) of the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="do not record the chain inside the timed region")
-    ap.add_argument("--sustain-seconds", type=float, default=2.5,
-                    help="after the K timed steps, a second run of about this many seconds (0 = skip)")
+    ap.add_argument("--sustain-seconds", type=float, default=10.0,
+                    help="after the K timed steps, a second run of about this many seconds (0 = skip); long enough for a "
+                         "driver that samples GPU activity every few seconds to land inside the kernel")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the RCCL communicator and run the exchange even with one rank (rehearsal)")
     ap.add_argument("--exchange-parts", default="auto",
@@ -481,11 +482,28 @@ def main():
         ens = build(1, kind="gloo_host")
         exchange_label = "FALLBACK: host-staged gloo all-gather (RCCL communicator failed: %s)" % comm_error
         exchange_kind = "gloo_host FALLBACK"
-    rccl_ranks = rccl_queried = None
+    rccl_ranks = rccl_queried = rccl_library = None
     if dist is not None and comm_error is None:
         _, rccl_ranks, rccl_queried = ctx.comm_info()
         exchange_kind = "rccl"
         exchange_label = f"in-library RCCL all-gather of the active colour, {ens.parts} piece(s) per half-step"
+        try:
+            rccl_library = vamp_amd.hip_backend.comm_library()      # the shared object whose ncclAllGather carried the bytes
+        except vamp_amd._lib.VampError as e:
+            rccl_library = "unknown (%s)" % e
+    # which physical device every rank ran on: a scaling line over N ranks must name N different devices
+    props = torch.cuda.get_device_properties(local_rank)
+    my_dev = {"rank": rank, "device_index": local_rank, "name": props.name,
+              "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
+    device_of_rank = [my_dev]
+    if dist is not None and world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, my_dev)
+        device_of_rank = box
+    # rehearsal knobs: with either of them a line over N ranks does NOT measure N GPUs over xGMI, and says so
+    knobs = {k: os.environ[k] for k in ("VAMP_RCCL_LIB", "VAMP_BENCH_DEVICE") if k in os.environ}
+    distinct = len({(d["uuid"] or d["pci_bus_id"] or d["device_index"]) for d in device_of_rank})
+    rehearsal = bool(knobs) or (world > 1 and distinct < world)
     own = ens.own_count
     host_staged = ens.exchange == "gloo_host"
 
@@ -616,8 +634,16 @@ def main():
                                            "~30 % of that arithmetic, so the nominal fraction can exceed 1"}},
             # how many ranks the exchange really spanned, and what it cost (rank 0's HIP events; half-step = one colour)
             "rccl_ranks": rccl_ranks,
+            # true: ranks shared a device and / or a stand-in carried the exchange (VAMP_BENCH_DEVICE, VAMP_RCCL_LIB): the
+            # code path of an N-GPU run, NOT a measurement of one
+            "rehearsal": rehearsal,
+            "rehearsal_knobs": knobs,
+            "device_of_rank": device_of_rank,
             "exchange": None if dist is None else {
                 "kind": exchange_kind, "parts": ens.parts, "rccl_ranks": rccl_ranks,
+                "rccl_library": rccl_library,
+                "rccl_library_is": "dladdr of the ncclAllGather the library bound (vamp_comm_library)",
+                "distinct_devices": distinct,
                 "rccl_ranks_is": None if rccl_ranks is None else (
                     "ncclCommCount of the library's communicator" if rccl_queried else "the world the communicator was created with"),
                 "bytes_per_rank_per_half_step": (own // 2) * (D + 1) * 8,

@@ -129,6 +129,12 @@ int vamp_set_regions(vamp_ctx* ctx, int n_regions, const int64_t* pix_off, const
  * region then follows the chain it follows in the single-context batch. */
 int vamp_set_region_ids(vamp_ctx* ctx, const int32_t* ids);
 
+/* Launch class of a region: 0 short (four walkers per wavefront), 1 blend (a wavefront and per-walker Taylor tables
+ * per walker), 2 wide (one walker per wavefront or per 4-wavefront workgroup), 3 short with one or two components
+ * (eight walkers per wavefront), 4 more than 16 components -- and the number of classes of the context (one launch
+ * per class and half-step).  Diagnostics: which kernels a context will run; see vamp_ctx_set_packing.  Either
+ * output may be NULL. */
+int vamp_region_class(vamp_ctx* ctx, int region, int* kind, int* n_classes);
 /* number of sampled dimensions of a region (q*K, +1 with sample_sd) */
 int vamp_region_ndim(vamp_ctx* ctx, int region, int* ndim);
 

@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "../include/vamp_hip.h"
+#include "../vamp_amd/csrc/host_plan.hpp"
 #include "../vamp_amd/csrc/map_search.hpp"
 #include "../vamp_amd/csrc/voigt_math.hpp"
 
@@ -118,6 +119,10 @@ struct vamp_ctx {
     bool timing = false;
     double timing_ms = 0.0;
     long long timing_launches = 0;
+    // the launch plan of the HIP library (csrc/host_plan.hpp), computed here too: nothing is launched on the host, but
+    // the product's own plan arithmetic runs -- under the sanitizers in the _asan build -- and vamp_region_class answers
+    int packing = 0;
+    vamp::plan::ClassPlan classes;
 };
 
 namespace {
@@ -391,7 +396,8 @@ int vamp_ctx_set_packing(vamp_ctx* c, int lanes) {
     if (!c) return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: ctx is NULL");
     if (lanes != 0 && lanes != 16 && lanes != 64 && lanes != 65 && lanes != 256)
         return fail(VAMP_ERR_ARG, "vamp_ctx_set_packing: lanes_per_walker must be 0 (auto), 16, 64, 65 (64 + per-walker tables) or 256");
-    return VAMP_OK;               // a launch shape: nothing to choose on the host
+    c->packing = lanes;           // a launch shape: nothing to launch on the host, but the class plan follows it
+    return VAMP_OK;
 }
 
 int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const double* x, const double* flux,
@@ -450,6 +456,12 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         }
         R[r] = d;
     }
+    {
+        std::vector<vamp::plan::RegionShape> shp(n_regions);
+        for (int r = 0; r < n_regions; ++r) shp[r] = vamp::plan::RegionShape{R[r].P, R[r].K};
+        const std::string err = vamp::plan::plan_classes(shp, c->packing, mode == VAMP_GAUSS3, c->f32, true, c->classes);
+        if (!err.empty()) return fail(VAMP_ERR_ARG, "vamp_set_regions: " + err);
+    }
     const long long N = pix_off[n_regions];
     c->x.assign(x, x + N);
     c->f.assign(flux, flux + N);
@@ -458,6 +470,14 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
     c->R = R;
     c->mode = mode;
     c->n_regions = n_regions;
+    return VAMP_OK;
+}
+
+int vamp_region_class(vamp_ctx* c, int region, int* kind, int* n_classes) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_region_class: ctx is NULL");
+    if (region < 0 || region >= c->n_regions) return fail(VAMP_ERR_ARG, "vamp_region_class: no such region");
+    if (kind) *kind = c->classes.kind[c->classes.class_of[region]];
+    if (n_classes) *n_classes = (int)c->classes.kind.size();
     return VAMP_OK;
 }
 
@@ -632,26 +652,26 @@ int vamp_sampler_set_shard_parts(vamp_ctx* c, int rank, int world, int parts, in
     if (parts < 1 || parts > 64) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: parts must be in 1..64");
     if (c->n_regions != 1) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: walker sharding is for single-region contexts (shard regions across devices otherwise)");
     if (c->comm && (world != 1 || rank != 0)) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: rank/world differ from the communicator's (vamp_comm_init_rank)");
-    const long long chunks = c->W / c->split_block;
-    if (chunks % ((long long)world * parts)) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: W/split_block must be a multiple of world * parts");
-    const long long cpp = chunks / ((long long)world * parts), hb = c->split_block / 2;
+    vamp::plan::ShardPlan sp;                       // csrc/host_plan.hpp: the arithmetic the HIP library runs
+    {
+        const std::string err = vamp::plan::plan_shard(c->W, c->split_block, rank, world, parts, sp);
+        if (!err.empty()) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: " + err);
+    }
     c->shard_rank = rank; c->shard_world = world; c->shard_parts = parts;
-    c->part_slots = cpp * hb;
-    c->part_stride = (chunks / parts) * hb;
-    c->slot_begin = rank * cpp * hb;
+    c->part_slots = sp.part_slots;
+    c->part_stride = sp.part_stride;
+    c->slot_begin = sp.slot_begin;
     c->slot_end = c->slot_begin + c->part_slots;
     c->send.clear(); c->recv.clear();
     if (world > 1 || c->comm) {
-        const size_t row = (size_t)c->R[0].D + 1;
-        c->send.assign((size_t)parts * c->part_slots * row, 0.0);
-        c->recv.assign((size_t)parts * world * c->part_slots * row, 0.0);
+        c->send.assign(vamp::plan::exchange_send_doubles(parts, c->part_slots, c->R[0].D), 0.0);
+        c->recv.assign(vamp::plan::exchange_recv_doubles(parts, world, c->part_slots, c->R[0].D), 0.0);
         c->part_step.assign(parts, 0u);
         c->part_half.assign(parts, 0);
     }
     for (int p = 0; p < parts; ++p) {
-        const long long first = p * (chunks / parts) + rank * cpp;
-        if (own_begin) own_begin[p] = first * c->split_block;
-        if (own_end) own_end[p] = (first + cpp) * c->split_block;
+        if (own_begin) own_begin[p] = sp.own_begin[p];
+        if (own_end) own_end[p] = sp.own_end[p];
     }
     return VAMP_OK;
 }
@@ -815,6 +835,17 @@ int vamp_sampler_scatter_put(vamp_ctx* c, int part, const double* rows_all) {
     if (part < 0 || part >= c->shard_parts) return fail(VAMP_ERR_ARG, "vamp_sampler_scatter_put: no such part");
     scatter_part(c, part, rows_all);
     return VAMP_OK;
+}
+
+// ---- test hooks (not part of the ABI: no vamp_ prefix): the launch-plan arithmetic of csrc/host_plan.hpp that no host
+//      entry point reaches, so that tests/test_cpu_boundary.py -- and its sanitizer run -- can drive it -----------------
+long long vampdbg_xcd_map(long long b, long long n_regions, long long bpr) { return vamp::plan::xcd_map(b, n_regions, bpr); }
+void vampdbg_packed_grid(long long n_regions, long long half_w, int subs, int waves_per_block, long long* out3) {
+    const vamp::plan::PackedGrid g = vamp::plan::plan_packed_grid(n_regions, half_w, subs, waves_per_block);
+    out3[0] = g.wpr; out3[1] = g.grid; out3[2] = g.bpr;
+}
+int vampdbg_resident_class_ok(int kind, long long half_w, int compute_waves, int walkers_per_wave, int automatic) {
+    return vamp::plan::resident_class_ok(kind, half_w, compute_waves, walkers_per_wave, automatic != 0) ? 1 : 0;
 }
 
 int vamp_exchange_timing(vamp_ctx* c, double* total_ms, int64_t* exchanges) {

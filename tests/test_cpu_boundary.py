@@ -167,3 +167,65 @@ def test_vpfit_facade_on_the_host_abi_matches_oracle(cpu_lib, voigt, n):
     assert np.allclose(g.bic_array, o.bic_array, rtol=1e-9, atol=0) and np.allclose(g.red_chi_array, o.red_chi_array, rtol=1e-9, atol=0)
     assert np.allclose(g.chain_covariance(n, voigt=voigt), o.chain_covariance(n, voigt=voigt), rtol=1e-7, atol=0)
     assert np.allclose(g.total.value, o.total.value, rtol=1e-9, atol=1e-300)
+
+
+def test_host_plan_launch_classes_shards_and_grids(cpu_lib, cpu_ctx):
+    """csrc/host_plan.hpp -- the launch-plan arithmetic of libvamp_hip.so (launch classes, shard and piece bounds,
+    exchange buffer sizes, wavefronts per region of packed launches, the region -> XCD mapping, the resident loop's
+    policy) -- through the host build of the ABI, which compiles the same header (and runs it under ASan / UBSan in
+    tests/test_sanitizers.py)."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    # launch classes of a spectrum-like context: blends, one- and two-line regions, the rest, a region of 20 lines
+    shapes = [(40, 1), (200, 4), (30, 5), (512, 8), (513, 8), (95, 3), (96, 3), (60, 2), (150, 20)] + [(20, 1)] * 8     # mean region <= 128 px
+    xs = [np.arange(P, dtype=np.float64) for P, _ in shapes]
+    cpu_ctx.set_packing(0)
+    cpu_ctx.set_regions(xs, [np.ones(P) for P, _ in shapes], [np.ones(P) for P, _ in shapes], [K for _, K in shapes], mode=1)
+    kinds, n_cls = cpu_ctx.region_classes()
+    assert kinds == [3, 1, 0, 1, 0, 0, 1, 3, 4] + [3] * 8 and n_cls == 4
+    short = [i for i in range(len(shapes)) if shapes[i][1] <= 8]
+    sub = lambda seq: [seq[i] for i in short]
+    cpu_ctx.set_regions(sub(xs), [np.ones(P) for P, _ in sub(shapes)], [np.ones(P) for P, _ in sub(shapes)], [K for _, K in sub(shapes)], mode=0)
+    assert cpu_ctx.region_classes() == ([3, 0, 0, 0, 0, 0, 0, 3] + [3] * 8, 2)          # Gaussian components: no tables, no blend class
+    long_x = [np.arange(2048, dtype=np.float64), np.arange(4096, dtype=np.float64)]
+    cpu_ctx.set_regions(long_x, [np.ones(x.size) for x in long_x], [np.ones(x.size) for x in long_x], [16, 3], mode=1)
+    assert cpu_ctx.region_classes() == ([2, 2], 1)
+    cpu_ctx.set_packing(16)
+    with pytest.raises(Exception, match="at most 8 components"):
+        cpu_ctx.set_regions(xs, [np.ones(P) for P, _ in shapes], [np.ones(P) for P, _ in shapes], [K for _, K in shapes], mode=1)
+    cpu_ctx.set_regions(sub(xs), [np.ones(P) for P, _ in sub(shapes)], [np.ones(P) for P, _ in sub(shapes)], [K for _, K in sub(shapes)], mode=1)
+    assert cpu_ctx.region_classes() == ([0] * 16, 1)
+    cpu_ctx.set_packing(0)
+    # shards and pieces: every slot of a half-step belongs to exactly one (rank, piece), in whole split chunks
+    x = np.arange(40, dtype=np.float64)
+    cpu_ctx.set_regions(x, np.ones(40), np.ones(40), 1, mode=1)
+    for W, block, world, parts in ((64, 8, 2, 2), (96, 4, 3, 4), (128, 2, 8, 8), (32, 32, 1, 1)):
+        X0 = np.column_stack([rng.uniform(0.5, 1, W), rng.uniform(5, 30, W), rng.uniform(1, 3, W), rng.uniform(2, 5, W)])
+        cpu_ctx.sampler_init(X0, seed=1, split_block=block)
+        owned = np.zeros(W, dtype=int)
+        for rank in range(world):
+            for b, e in cpu_ctx.sampler_set_shard_parts(rank, world, parts):
+                assert b % block == 0 and e % block == 0 and e - b == W // (world * parts)
+                owned[b:e] += 1
+            if world > 1:
+                assert cpu_ctx.pack_get(0).shape == (W // 2 // (world * parts), 5)
+        assert np.all(owned == 1)
+    with pytest.raises(Exception, match="multiple of world"):
+        cpu_ctx.sampler_set_shard_parts(0, 3, 1)
+    # packed launches: wavefronts per region, and the region -> XCD mapping is a bijection that keeps a region on one XCD
+    cpu_lib.vampdbg_xcd_map.restype = C.c_longlong
+    cpu_lib.vampdbg_xcd_map.argtypes = [C.c_longlong] * 3
+    out3 = (C.c_longlong * 3)()
+    for n_reg, half_w, subs, wpb in ((361, 8192, 8, 2), (54, 8192, 1, 1), (6, 100, 4, 2), (17, 35, 8, 2), (8, 16, 8, 2)):
+        cpu_lib.vampdbg_packed_grid(C.c_longlong(n_reg), C.c_longlong(half_w), subs, wpb, out3)
+        wpr, grid, bpr = out3[0], out3[1], out3[2]
+        assert wpr == -(-half_w // subs) and grid == -(-n_reg * wpr // wpb) and bpr == (wpr // wpb if wpr % wpb == 0 else 0)
+        if bpr:
+            mapped = [cpu_lib.vampdbg_xcd_map(b, n_reg, bpr) for b in range(grid)]
+            assert sorted(mapped) == list(range(grid))
+            for b, lb in enumerate(mapped[:(n_reg - n_reg % 8) * bpr]):
+                assert (lb // bpr) % 8 == b % 8                      # region i runs on XCD i % 8
+    assert cpu_lib.vampdbg_xcd_map(5, 100, 0) == 5
+    # the resident loop's automatic policy: packed short-region classes, every mover in one round
+    ok = cpu_lib.vampdbg_resident_class_ok
+    assert ok(3, 16, 2, 8, 1) == 1 and ok(3, 17, 2, 8, 1) == 0 and ok(1, 16, 8, 1, 1) == 0 and ok(1, 16, 8, 1, 0) == 1 and ok(0, 16, 0, 4, 0) == 0

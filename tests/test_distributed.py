@@ -562,6 +562,26 @@ def test_bench_plain_form_launches_its_own_ranks(n):
     assert line["value"] > 0 and 0.05 < line["acceptance_fraction"] < 0.95 and line["finite_lnprob_fraction"] == 1.0
     assert line["roofline"]["walker_steps_per_launch"] == 4096 // n // 2 // ex["parts"]
     assert line["sustained"]["steps"] >= 2 and line["sustained"]["value"] > 0
+    # the line proves what carried its bytes and where its ranks ran: this is a rehearsal and says so
+    assert line["rehearsal"] is True and line["rehearsal_knobs"] == {"VAMP_BENCH_DEVICE": "0", "VAMP_RCCL_LIB": FAKE_RCCL}
+    assert os.path.samefile(ex["rccl_library"], FAKE_RCCL)
+    assert len(line["device_of_rank"]) == n and ex["distinct_devices"] == 1
+    assert sorted(d["rank"] for d in line["device_of_rank"]) == list(range(n)) and {d["device_index"] for d in line["device_of_rank"]} == {0}
+
+
+@pytest.mark.gpu
+def test_bench_driver_form_is_not_a_rehearsal():
+    """The N = 1 form the driver runs: no knob in the environment -> `rehearsal` false, one device named; with
+    --force-dist the exchange runs over the REAL RCCL of the ROCm runtime the library is bound to, and the line
+    names that file."""
+    env = {}
+    line, _ = _run_bench(BENCH_SMALL, env)
+    assert line["n_gpus"] == 1 and line["rehearsal"] is False and line["rehearsal_knobs"] == {} and line["exchange"] is None
+    assert len(line["device_of_rank"]) == 1 and line["device_of_rank"][0]["device_index"] == 0
+    line, _ = _run_bench(["--force-dist"] + BENCH_SMALL, env)
+    ex = line["exchange"]
+    assert line["rehearsal"] is False and line["rccl_ranks"] == 1 and ex["kind"] == "rccl"
+    assert "librccl" in os.path.basename(ex["rccl_library"]) and ex["distinct_devices"] == 1
 
 
 @pytest.mark.gpu

@@ -36,6 +36,7 @@ SIGNATURES = {
     "vamp_set_regions": (C.c_int, [C.c_void_p, C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_int32_p,
                                    C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),
     "vamp_set_region_ids": (C.c_int, [C.c_void_p, c_int32_p]),
+    "vamp_region_class": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vamp_region_ndim": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "vamp_lnprob": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p, c_double_p, c_double_p]),
     "vamp_lnprob_all": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),

@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "../../include/vamp_hip.h"
+#include "host_plan.hpp"
 #include "map_search.hpp"
 #include "voigt_math.hpp"
 
@@ -65,6 +66,12 @@
 #endif
 #ifndef VAMP_SR_EARLY
 #define VAMP_SR_EARLY 0
+#endif
+#ifndef VAMP_XCD_MAP
+#define VAMP_XCD_MAP 0        // region -> XCD mapping of multi-region launches: measured, off (k_half_step; profiles/r04_d_xcd_mapping.txt)
+#endif
+#ifndef VAMP_F32_LEAN_STAGE
+#define VAMP_F32_LEAN_STAGE 1
 #endif
 namespace {
 
@@ -306,6 +313,13 @@ __device__ __forceinline__ double xexp_logp(double v) {
     if (v <= 700.0) return log(v) - v;
     return log(v * exp(-v));
 }
+// the same in fp32 contexts: the logarithm in single precision (~1e-7 of a term of order 1 in a log-posterior whose
+// chi^2 carries W4's 1e-4; the stated tolerance is 1e-3 of chi^2), v itself subtracted in double
+__device__ __forceinline__ double xexp_logp32(double v) {
+    if (!(v >= 0.0) || !isfinite(v)) return NEG_INF;
+    if (v <= 700.0) return (double)__logf((float)v) - v;
+    return log(v * exp(-v));
+}
 __device__ __forceinline__ double uniform_logp(double v, double lo, double hi, double lp) {
     return (v >= lo && v <= hi) ? lp : NEG_INF;
 }
@@ -327,15 +341,20 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
     double lp = 0.0;
     const int K = R.K;
     constexpr int Q = (MODE == VAMP_VOIGT4) ? 4 : 3;
+    // fp32 contexts (VAMP_F32_LEAN_STAGE): the amplitude prior's logarithm in single precision, and no pole factor /
+    // h y where no near-axis table will be built from them (Humlicek's W4 reads neither) -- the staging is ~1/4 of a
+    // short region's half-step in fp32 (profiles/r04_c_small_ensembles.txt, stamps 2 -> 3)
+    const bool lean = VAMP_F32_LEAN_STAGE && want_f32;
+    const bool need_core = !(VAMP_F32_LEAN_STAGE && want_f32 && !TAB32 && !DT32);
     if (lane < K && writer) {
         const double* t = &L.theta[Q * lane];
         double a, c, Lw = 0.0, G = 0.0, sg = 0.0;
         if constexpr (MODE == VAMP_GAUSS3) {
             a = t[0]; c = t[1]; sg = t[2];
-            lp = xexp_logp(a) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) + uniform_logp(sg, 0.0, R.w_max, R.lp_w);
+            lp = (lean ? xexp_logp32(a) : xexp_logp(a)) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) + uniform_logp(sg, 0.0, R.w_max, R.lp_w);
         } else if constexpr (MODE == VAMP_VOIGT4) {
             a = t[0]; c = t[1]; Lw = t[2]; G = t[3];
-            lp = xexp_logp(a) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) +
+            lp = (lean ? xexp_logp32(a) : xexp_logp(a)) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) +
                  uniform_logp(Lw, 0.0, R.w_max, R.lp_w) + uniform_logp(G, 0.0, R.w_max, R.lp_w);
         } else {   // NBZ3: inverse of physics.py:15,27,120,134
             const double sig = t[1] * 1.0e3 * 1.41421356237309514547 / (2.355 * (R.line * 1.0e-10));
@@ -343,7 +362,7 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
             c = (C_LIGHT / (R.line * (1.0 + t[2]) * 1.0e-10) - R.x_origin) / R.x_scale;
             G = (sig / R.x_scale) * FWHM_PER_SIGMA;
             Lw = R.l_fixed;
-            lp = xexp_logp(a) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) + uniform_logp(G, 0.0, R.w_max, R.lp_w);
+            lp = (lean ? xexp_logp32(a) : xexp_logp(a)) + uniform_logp(c, R.c_lo, R.c_hi, R.lp_c) + uniform_logp(G, 0.0, R.w_max, R.lp_w);
         }
         LineRec rec;
         rec.c = c;
@@ -355,8 +374,8 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
             rec.s = (2.0 * SQRT_LN2) * rG;
             rec.y = (Lw * SQRT_LN2) * rG;
             rec.amp = a * rec.y;
-            rec.pole = vamp::core_pole_factor(rec.y);
-            rec.hy = vamp::core_hy(rec.y);
+            rec.pole = need_core ? vamp::core_pole_factor(rec.y) : 0.0;
+            rec.hy = need_core ? vamp::core_hy(rec.y) : 0.0;
             // packed waves: another walker of the wave may force a deep fraction on this one, so every
             // line is capped there
             rec.xcap = (PK::SUBS == 1 && rec.s * R.tile_span <= 16.0) ? __builtin_huge_val() : vamp::X_FAR;   // NaN -> capped
@@ -1829,6 +1848,8 @@ struct SamplerDev {
     const int* region_list;      // this launch's regions (a launch class of the ctx), or nullptr = all, in order
     double* pack;                // walker-sharded runs: [slot - slot_begin][D + 1] = the mover's row and lnprob
                                  // after the accept step (what the other devices need), else nullptr
+    int bpr, n_cls_regions;      // several regions: workgroups per region (0: workgroups do not align with regions) and the
+                                 // regions of this launch, for the region -> XCD mapping of k_half_step
     int wpr;                     // packed shapes, several regions: wavefronts per region = ceil((W/2) / SUBS), so that every
                                  // wavefront lies inside one region whatever W is (the last one of a region may have idle
                                  // groups); 0: slots are dealt to wavefronts linearly (one region, or one walker per wavefront)
@@ -1968,11 +1989,24 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_st
     const int sub = lane / PK::LPW, l = lane % PK::LPW;
     const long long halfW = S.W >> 1;
     // first walker of this wave (a split workgroup: the one walker all of its waves serve)
-    long long slot0 = PK::SPLIT ? (long long)blockIdx.x : ((long long)blockIdx.x * PK::WPB + wave) * PK::SUBS;
+    // Workgroups are dealt round-robin to the eight XCDs (workgroup b runs on XCD b % 8), each with its own L2.  In a
+    // context of several regions the movers of a region read rows of that region only, so a mapping that keeps a
+    // region on ONE XCD (-DVAMP_XCD_MAP=1: region i of the launch on XCD i % 8, vamp::plan::xcd_map) fetches its state
+    // into one L2 instead of up to eight.  MEASURED on q1422 (profiles/r04_d_xcd_mapping.txt): FETCH_SIZE per half-step
+    // 782 -> 309 MB (TCC misses 11.8 M -> 5.0 M) as predicted -- and 3.64 ms against 3.37 per half-step in fp64, 1.84
+    // against 1.71 in fp32: regions differ in cost (the 54 blends: 3 .. 8 lines over 96 .. 512 px, six or seven per
+    // XCD), the round-robin deal balances them and the mapping does not; contiguous eighths of the launch per XCD
+    // were worse still (4.13 ms).  These kernels are bound by instruction issue, not by the row gathers.  Off.
+    // (One region -- the headline: every workgroup reads the same spectrum and random rows of one state: nothing to align.)
+    long long b = blockIdx.x;
+#if VAMP_XCD_MAP
+    if (DRAWS != DRAW_HOST && S.bpr > 0) b = vamp::plan::xcd_map(b, S.n_cls_regions, S.bpr);   // (the last n % 8 regions keep their place)
+#endif
+    long long slot0 = PK::SPLIT ? b : (b * PK::WPB + wave) * PK::SUBS;
     if (PK::SUBS > 1 && DRAWS != DRAW_HOST && S.wpr > 0) {
         // several regions, several walkers per wavefront: wavefront g serves SUBS consecutive movers of region
         // g / wpr; the groups beyond the region's W/2 movers idle (below: slot0 + sub leaves the region's range)
-        const long long g = (long long)blockIdx.x * PK::WPB + wave;
+        const long long g = b * PK::WPB + wave;
         const long long ri = g / S.wpr;
         slot0 = ri * halfW + (g - ri * S.wpr) * PK::SUBS;
         if (slot0 + sub >= (ri + 1) * halfW) return;
@@ -2192,7 +2226,7 @@ inline unsigned shape_threads(int sh) {
 // A launch class: the regions of a context that one kernel shape serves.  Real spectra mix many
 // short single-line regions (four walkers per wavefront) with a few long blends (a wavefront per
 // walker with Taylor tables); each class is one launch per half-step over its own region list.
-enum ClassKind { CK_SMALL = 0, CK_MID = 1, CK_WIDE = 2, CK_SMALL2 = 3, CK_XL = 4 };
+using vamp::plan::CK_SMALL; using vamp::plan::CK_MID; using vamp::plan::CK_WIDE; using vamp::plan::CK_SMALL2; using vamp::plan::CK_XL;
 struct LaunchClass {
     int kind = CK_WIDE;
     std::vector<int> regions;
@@ -2353,9 +2387,9 @@ int flush_exchange_timing(vamp_ctx* c) {
 // position + lnprob per row (+ the per-part events when a communicator will run the exchange)
 int ensure_part_events(vamp_ctx* c, int parts);
 int alloc_exchange_buffers(vamp_ctx* c) {
-    const size_t row = (size_t)c->regions_h[0].D + 1;
-    HIP_TRY(hipMalloc(&c->send_d, (size_t)c->shard_parts * c->part_slots * row * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->recv_d, (size_t)c->shard_parts * c->shard_world * c->part_slots * row * sizeof(double)));
+    const int D = c->regions_h[0].D;
+    HIP_TRY(hipMalloc(&c->send_d, vamp::plan::exchange_send_doubles(c->shard_parts, c->part_slots, D) * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->recv_d, vamp::plan::exchange_recv_doubles(c->shard_parts, c->shard_world, c->part_slots, D) * sizeof(double)));
     c->part_step.assign(c->shard_parts, 0u);
     c->part_half.assign(c->shard_parts, 0);
     if (c->comm) return ensure_part_events(c, c->shard_parts);
@@ -2421,7 +2455,7 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     S.n_accept = c->nacc_d;
     S.region_list = nullptr;
     S.slot_begin = S.slot_end = 0;
-    S.wpr = 0;
+    S.wpr = S.bpr = S.n_cls_regions = 0;
     S.pack = (!ext && c->send_d) ? c->send_d + (long long)part * c->part_slots * (c->regions_h[0].D + 1) : nullptr;
     if (!ext && c->send_d) {
         c->part_step[part] = (unsigned)c->step;
@@ -2497,12 +2531,17 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
         // (a shard or a piece of a single-region ensemble takes the shape of the WHOLE ensemble)
         const int shape = class_shape(c, cl, (!ext && c->n_regions == 1) ? halfW : n, packable);
         unsigned grid = (unsigned)((n + shape_walkers_per_block(shape) - 1) / shape_walkers_per_block(shape));
-        S.wpr = 0;
+        S.wpr = S.bpr = 0;
+        S.n_cls_regions = (int)cl.regions.size();
         if (!ext && c->n_regions > 1 && (shape == SH_SMALL || shape == SH_SMALL2)) {
-            const long long subs = shape == SH_SMALL ? PackSmall::SUBS : PackSmall2::SUBS;
-            const long long wpb = shape == SH_SMALL ? PackSmall::WPB : PackSmall2::WPB;
-            S.wpr = (int)((halfW + subs - 1) / subs);
-            grid = (unsigned)(((long long)cl.regions.size() * S.wpr + wpb - 1) / wpb);
+            const vamp::plan::PackedGrid pg = vamp::plan::plan_packed_grid((long long)cl.regions.size(), halfW,
+                                                                           shape == SH_SMALL ? PackSmall::SUBS : PackSmall2::SUBS,
+                                                                           shape == SH_SMALL ? PackSmall::WPB : PackSmall2::WPB);
+            S.wpr = pg.wpr;
+            S.bpr = pg.bpr;
+            grid = (unsigned)pg.grid;
+        } else if (!ext && c->n_regions > 1 && halfW % shape_walkers_per_block(shape) == 0) {
+            S.bpr = (int)(halfW / shape_walkers_per_block(shape));        // one walker per wavefront or per workgroup
         }
         const dim3 threads(shape_threads(shape));
         if (ext) {
@@ -2596,8 +2635,7 @@ bool resident_eligible(const vamp_ctx* c) {
     for (const LaunchClass& cl : c->classes) {
         const int shape = class_shape(c, cl, class_movers(c, cl), true);
         const int nw = resident_waves_for(c, shape, halfW);
-        if (nw <= 0) return false;
-        if (c->opt_resident == 1 && (!(cl.kind == CK_SMALL || cl.kind == CK_SMALL2) || nw * shape_walkers_per_block(shape) / shape_waves(shape) < halfW))
+        if (!vamp::plan::resident_class_ok(cl.kind, halfW, nw, (int)(shape_walkers_per_block(shape) / shape_waves(shape)), c->opt_resident == 1))
             return false;
     }
     return true;
@@ -3108,52 +3146,29 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
     HIP_TRY(hipMalloc(&c->regions_d, n_regions * sizeof(RegionDev)));
     HIP_TRY(hipMemcpy(c->regions_d, R.data(), n_regions * sizeof(RegionDev), hipMemcpyHostToDevice));
     {
-        // regions of more than KMAX lines form their own class (plain shape PackXL); everything below is about the others
-        int kmax = 0, n_std = 0;
-        long long pix_std = 0;
-        c->full_tiles = true;
-        c->min_tiles = 0x7fffffff;
-        for (int r = 0; r < n_regions; ++r) {
-            if (R[r].K > KMAX) continue;
-            kmax = std::max(kmax, R[r].K);
-            n_std += 1;
-            pix_std += R[r].P;
-            c->full_tiles = c->full_tiles && (R[r].P % (64 * TPIX) == 0);
-            c->min_tiles = std::min(c->min_tiles, R[r].P / (64 * TPIX));
+        // launch classes (csrc/host_plan.hpp, shared with the host build of this ABI).  Forced packings: one class.
+        // Automatic: contexts that look like a real spectrum (<= 8 lines in every region of <= 16, mean region
+        // <= 128 px) split into the blends worth a wavefront and a set of Taylor tables per walker (>= 3 lines over
+        // 96 .. 512 px: table building costs ~2 near-axis evaluations per line and interval, repaid from ~30 px per
+        // line on), the one- and two-line regions (eight walkers per wavefront) and the rest (four); regions of more
+        // than 16 lines form their own class (plain shape PackXL); everything else is one wide class.
+        vamp::plan::Limits lim;
+        static_assert(KMAX == 16 && KMAX_ALL == 32 && PackSmall::KCAP == 8 && PackSmall2::KCAP == 2 && VAMP_MID_MIN_K == 3 &&
+                      VAMP_MID_MIN_P == 96 && BLEND_MAX_PIXELS == 512 && 64 * TPIX == 256, "vamp::plan::Limits describes these shapes");
+        std::vector<vamp::plan::RegionShape> shp(n_regions);
+        for (int r = 0; r < n_regions; ++r) shp[r] = vamp::plan::RegionShape{R[r].P, R[r].K};
+        vamp::plan::ClassPlan cp;
+        const std::string err = vamp::plan::plan_classes(shp, c->packing, mode == VAMP_GAUSS3, c->f32, VAMP_F32_TABLES != 0, cp, lim);
+        if (!err.empty()) return fail(VAMP_ERR_ARG, "vamp_set_regions: " + err);
+        c->full_tiles = cp.full_tiles;
+        c->min_tiles = cp.min_tiles;
+        c->class_of = cp.class_of;
+        for (size_t k = 0; k < cp.kind.size(); ++k) {
+            LaunchClass cl;
+            cl.kind = cp.kind[k];
+            cl.regions = cp.regions[k];
+            c->classes.push_back(cl);
         }
-        if (n_std == 0) c->min_tiles = 0;
-        const double mean_p = n_std ? (double)pix_std / n_std : 0.0;
-        if ((c->packing == 16 || c->packing == 65) && (kmax > PackSmall::KCAP || n_std < n_regions))
-            return fail(VAMP_ERR_ARG, "vamp_set_regions: packings 16 and 65 support at most 8 components per region");
-        // launch classes.  Forced packings: one class.  Automatic: contexts that look like a real
-        // spectrum (<= 8 lines everywhere, mean region <= 128 px) split into the blends worth a
-        // wavefront and a set of Taylor tables per walker (>= 3 lines over >= 96 px: table building
-        // costs ~2 near-axis evaluations per line and interval, repaid from ~30 px per line on) and
-        // the rest, four walkers to a wavefront; everything else is one wide class.
-        c->class_of.assign(n_regions, 0);
-        // (judged over the regions of <= KMAX lines only: a region of 17+ lines has its own class whatever the others run)
-        const bool spectrum_like = c->packing == 0 && n_std > 0 && kmax <= PackSmall::KCAP && mean_p <= 128.0;
-        LaunchClass cls[4];
-        cls[0].kind = c->packing == 16 ? CK_SMALL : c->packing == 65 ? CK_MID : spectrum_like ? CK_SMALL : CK_WIDE;
-        cls[1].kind = CK_MID;
-        cls[2].kind = CK_SMALL2;
-        cls[3].kind = CK_XL;
-        for (int r = 0; r < n_regions; ++r) {
-            int k = 0;
-            if (R[r].K > KMAX) {
-                k = 3;
-            } else if (spectrum_like) {
-                if (R[r].K >= VAMP_MID_MIN_K && R[r].P >= VAMP_MID_MIN_P && R[r].P <= BLEND_MAX_PIXELS && mode != VAMP_GAUSS3 &&
-                    (!c->f32 || VAMP_F32_TABLES)) k = 1;
-                else if (R[r].K <= PackSmall2::KCAP) k = 2;
-            }
-            cls[k].regions.push_back(r);
-        }
-        for (int k : {1, 2, 0, 3})       // blends first: the longest launch starts first when the classes overlap
-            if (!cls[k].regions.empty()) {
-                for (int r : cls[k].regions) c->class_of[r] = (int)c->classes.size();
-                c->classes.push_back(cls[k]);
-            }
         if (c->classes.size() > 1)
             for (LaunchClass& cl : c->classes) {
                 HIP_TRY(hipMalloc(&cl.list_d, cl.regions.size() * sizeof(int)));
@@ -3176,6 +3191,14 @@ int vamp_set_region_ids(vamp_ctx* c, const int32_t* ids) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int r = 0; r < c->n_regions; ++r) c->regions_h[r].rng_id = ids[r];
     HIP_TRY(hipMemcpy(c->regions_d, c->regions_h.data(), c->n_regions * sizeof(RegionDev), hipMemcpyHostToDevice));
+    return VAMP_OK;
+}
+
+int vamp_region_class(vamp_ctx* c, int region, int* kind, int* n_classes) {
+    if (!c) return fail(VAMP_ERR_ARG, "vamp_region_class: ctx is NULL");
+    if (region < 0 || region >= c->n_regions) return fail(VAMP_ERR_ARG, "vamp_region_class: no such region");
+    if (kind) *kind = c->classes[c->class_of[region]].kind;
+    if (n_classes) *n_classes = (int)c->classes.size();
     return VAMP_OK;
 }
 
@@ -3512,18 +3535,18 @@ int vamp_sampler_set_shard_parts(vamp_ctx* c, int rank, int world, int parts, in
     if (c->n_regions != 1) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: walker sharding is for single-region contexts (shard regions across devices otherwise)");
     if (c->comm && (world != c->comm_world || rank != c->comm_rank))
         return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: rank/world differ from the communicator's (vamp_comm_init_rank)");
-    const long long chunks = c->W / c->split_block;
-    if (chunks % ((long long)world * parts)) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: W/split_block must be a multiple of world * parts");
-    // the ensemble is cut into `parts` equal row ranges and each of those into `world` shards:
-    // part p of rank r = chunks [p * chunks/parts + r * cpp, ... + cpp)
-    const long long cpp = chunks / ((long long)world * parts);
-    const long long hb = c->split_block / 2;
+    // the ensemble is cut into `parts` equal row ranges and each of those into `world` shards (csrc/host_plan.hpp)
+    vamp::plan::ShardPlan sp;
+    {
+        const std::string err = vamp::plan::plan_shard(c->W, c->split_block, rank, world, parts, sp);
+        if (!err.empty()) return fail(VAMP_ERR_ARG, "vamp_sampler_set_shard: " + err);
+    }
     c->shard_rank = rank;
     c->shard_world = world;
     c->shard_parts = parts;
-    c->part_slots = cpp * hb;
-    c->part_stride = (chunks / parts) * hb;
-    c->slot_begin = rank * cpp * hb;
+    c->part_slots = sp.part_slots;
+    c->part_stride = sp.part_stride;
+    c->slot_begin = sp.slot_begin;
     c->slot_end = c->slot_begin + c->part_slots;      // of part 0
     // exchange buffers: the movers of every part in slot order, position + lnprob per row
     HIP_TRY(hipSetDevice(c->device));
@@ -3536,9 +3559,8 @@ int vamp_sampler_set_shard_parts(vamp_ctx* c, int rank, int world, int parts, in
         if (rc) return rc;
     }
     for (int p = 0; p < parts; ++p) {
-        const long long first = p * (chunks / parts) + rank * cpp;
-        if (own_begin) own_begin[p] = first * c->split_block;
-        if (own_end) own_end[p] = (first + cpp) * c->split_block;
+        if (own_begin) own_begin[p] = sp.own_begin[p];
+        if (own_end) own_end[p] = sp.own_end[p];
     }
     return VAMP_OK;
 }

@@ -209,6 +209,16 @@ class HipContext:
         self.n_pix = [len(a) for a in xs]
         self.n_comp = [int(k) for k in n_comp]
 
+    def region_classes(self):
+        """launch class of every region (vamp_region_class: 0 short, 1 blend, 2 wide, 3 short with <= 2 lines, 4 more
+        than 16 lines) and the number of classes of the context"""
+        k, n = C.c_int(0), C.c_int(0)
+        kinds = []
+        for r in range(self.n_regions):
+            self._check(self._lib.vamp_region_class(self._h, r, C.byref(k), C.byref(n)))
+            kinds.append(k.value)
+        return kinds, n.value
+
     def set_region_ids(self, ids):
         """Global identity of every region in the draw keys (see vamp_set_region_ids)."""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
