@@ -70,6 +70,12 @@
 #ifndef VAMP_XCD_MAP
 #define VAMP_XCD_MAP 0        // region -> XCD mapping of multi-region launches: measured, off (k_half_step; profiles/r04_d_xcd_mapping.txt)
 #endif
+#ifndef VAMP_WIDE_NODES
+#define VAMP_WIDE_NODES 1      // lines far wider than a tile join the tile's interpolant (sweep_range_ff)
+#endif
+#ifndef VAMP_WIDE_MAX
+#define VAMP_WIDE_MAX 0.5      // ... when the tile's half-width is at most this many units of the line's z
+#endif
 #ifndef VAMP_F32_LEAN_STAGE
 #define VAMP_F32_LEAN_STAGE 1
 #endif
@@ -247,6 +253,7 @@ struct alignas(16) TileScratch {   // per wavefront: far-field working set of th
     int farlist[KMAX];      // lines treated through the far field, as byte offsets of their records (fp64: LineRec,
                             // fp32: linef rows) -- the list is read four times per tile, an index would cost a
                             // quarter-rate 32-bit multiply each time
+    int widelist[KMAX];     // near lines far WIDER than the tile (fp64 tables shape): line indices
 };
 // Taylor tables of the near-axis zone of every line of ONE walker (voigt_math.hpp): 28 KiB, which
 // only a workgroup that serves a single walker can afford (4 workgroups per CU).
@@ -338,6 +345,8 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
     // line -- was 3 % of its instructions three times over.)
     const bool writer = !PK::SPLIT || part == 0;
     constexpr int LP_SLOT = 4 * PK::KCAP + 3;       // theta holds at most 4 KCAP + 1 parameters
+    constexpr int WIDE_SLOT = 4 * PK::KCAP + 2;     // far-field shapes: bit k set = line k is far wider than a tile (ff_wide_nodes)
+    bool my_wide = false;
     double lp = 0.0;
     const int K = R.K;
     constexpr int Q = (MODE == VAMP_VOIGT4) ? 4 : 3;
@@ -382,6 +391,8 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
             if constexpr (PK::FF) {
                 rec.w8 = sqrt(fmax(vamp::R2_CORE - rec.y * rec.y, 0.0)) / rec.s;
                 rec.w25 = sqrt(fmax(vamp::R2_M3 - rec.y * rec.y, 0.0)) / rec.s;
+                // half of the region's widest tile is at most VAMP_WIDE_MAX in this line's z: smooth across every tile
+                my_wide = VAMP_WIDE_NODES && TAB && rec.s * (0.5 * R.tile_span) <= VAMP_WIDE_MAX;
             } else {
                 rec.w8 = rec.w25 = 0.0;
             }
@@ -395,6 +406,10 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
             L.linef[lane][2] = (float)rec.y;
             L.linef[lane][3] = (float)(MODE == VAMP_GAUSS3 ? rec.amp : rec.amp * SQRT_PI);   // W4 returns H itself
         }
+    }
+    if constexpr (PK::FF && TAB && VAMP_WIDE_NODES) {
+        const unsigned long long wm = __ballot(my_wide);
+        if (writer && lane == 0) L.theta[WIDE_SLOT] = __longlong_as_double((long long)wm);
     }
     if (R.sample_sd && lane == PK::KCAP && writer) {      // one otherwise idle lane: sd ~ U(0,1), vpfits.py:39
         lp = uniform_logp(L.theta[R.D - 1], 0.0, 1.0, 0.0);
@@ -786,7 +801,7 @@ __device__ __forceinline__ void ff_series(TileScratch& Sx, const double* __restr
 //     (fp32 contexts: ff32_coefficients below, 8 nodes)
 template <class LDS>
 __device__ __forceinline__ void ff_coefficients(const LDS& L, TileScratch& Sx, const double* __restrict__ dct,
-                                                int lane, int nfar, double mid, double half) {
+                                                int lane, int nfar, double mid, double half, double fs_wide = 0.0) {
     const int node = lane & (FF_NODES - 1), grp = lane >> 4;
     const double tnode = dct[FF_MAT + node];                       // cos(pi (node + 1/2) / 16)
     __builtin_amdgcn_wave_barrier();
@@ -796,13 +811,13 @@ __device__ __forceinline__ void ff_coefficients(const LDS& L, TileScratch& Sx, c
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int q = 4 * t + grp;
-        const LineRec& ln = *reinterpret_cast<const LineRec*>(reinterpret_cast<const char*>(L.line) + Sx.farlist[q < nfar ? q : nfar - 1]);
+        const LineRec& ln = *reinterpret_cast<const LineRec*>(reinterpret_cast<const char*>(L.line) + (nfar > 0 ? Sx.farlist[q < nfar ? q : nfar - 1] : 0));
         Xn[t] = fabs(xnode - ln.c) * ln.s;
         yn[t] = ln.y;
         an[t] = q < nfar ? ln.amp : 0.0;
     }
-    double fs;
-    {
+    double fs = 0.0;
+    if (nfar > 0) {
         const double Xa[2] = {Xn[0], Xn[1]}, ya[2] = {yn[0], yn[1]};
         double Ha[2];
         ff_eval2(Xa, ya, Ha, dct + FF_EXP);
@@ -814,9 +829,42 @@ __device__ __forceinline__ void ff_coefficients(const LDS& L, TileScratch& Sx, c
         ff_eval2(Xb, yb, Hb, dct + FF_EXP);
         fs += fma(an[2], Hb[0], an[3] * Hb[1]);
     }
+    fs += fs_wide;
     fs += __shfl_xor(fs, 16, 64);
     fs += __shfl_xor(fs, 32, 64);
     ff_series<double>(Sx, dct, lane, fs);
+}
+// ---- lines far wider than the tile -------------------------------------------------------------------------------
+// An ensemble drawn from the priors (widths ~ U(0, fwhm_max): where every find_bic repeat STARTS, vpfits.py:283-297) has
+// nothing far: every line is wider than the region, every (line, tile) pair is near and costs four table look-ups per
+// lane (profiles/r03_c_headline_robustness.txt: 12.5 ms per swept half-step against 3.4).  But seen from a tile, such a
+// line is as smooth as a far one: w is entire, and over a tile whose half-width is at most VAMP_WIDE_MAX = 1/2 in the
+// line's own z the degree-15 interpolant through the tile's 16 Chebyshev nodes reproduces its optical depth to ~1e-14
+// (coefficients fall like (a/2)^n / sqrt(n!)).  So the roles of "far" and "wide" are exchanged: wide lines are evaluated
+// at the NODES -- (node, line) pairs over the lanes as for the far lines, 4 lines per lane, through the line's own
+// Taylor table (or the 6-level fraction beyond |z| = 8) -- and join the far lines' node sums before the one transform.
+// 16 wide lines: 4 look-ups per lane and tile instead of 64.
+template <class LDS>
+__device__ __forceinline__ double ff_wide_nodes(const LDS& L, const TileScratch& Sx, const double* __restrict__ dct, const double* tab,
+                                                int lane, int nwide, double mid, double half) {
+    const int node = lane & (FF_NODES - 1), grp = lane >> 4;
+    const double xnode = fma(half, dct[FF_MAT + node], mid);
+    double fs = 0.0;
+    for (int t = 0; 4 * t < nwide; ++t) {
+        const int q = 4 * t + grp;
+        const int k = Sx.widelist[q < nwide ? q : nwide - 1];
+        const LineRec& ln = L.line[k];
+        const double X = fabs(xnode - ln.c) * ln.s, r2 = fma(X, X, ln.y * ln.y);
+        double H;
+        if (r2 < vamp::R2_CORE) {
+            H = table_eval(tab + k * vamp::TAB_LINE, X);
+        } else {
+            H = vamp::voigt_jfrac<6>(X, ln.y, r2);
+            if (ln.y < vamp::Y_TINY) H += vamp::SQRT_PI * vamp::exp_neg_sq_tab(X, dct + FF_EXP);
+        }
+        fs = fma(q < nwide ? ln.amp : 0.0, H, fs);
+    }
+    return fs;
 }
 // (c) Horner's rule at the tile's pixels, added to tau (in the pixel arithmetic type).  Register t of a
 //     lane is pixel 64 t + lane of the tile: quarter t of an ascending grid, 3 - t of a descending one.
@@ -844,11 +892,14 @@ __device__ __forceinline__ void ff_horner(const TileScratch& Sx, const real (&xi
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int MODE, class PK, bool TAB>
+// WIDE: this walker has lines far wider than a tile (ff_wide_nodes).  A copy of the loop of its own, chosen per walker
+// by a wave-uniform branch: compiled into the one loop, the wide path cost the converged headline ensemble -- which has no
+// such line -- 2.8 % through the loop's register allocation (profiles/r04_e_wide_lines.txt).
+template <int MODE, class PK, bool TAB, bool WIDE = false>
 __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const typename PK::Lds& L, TileScratch& Sx, const double* __restrict__ dct,
                                                const double* __restrict__ x, const double* __restrict__ f,
                                                const double* __restrict__ wt, int lane, int base0, int base1, int stride,
-                                               double& chi, const double* tab) {
+                                               double& chi, const double* tab, unsigned long long wide_all = 0ull) {
     constexpr int T = TPIX;
     static_assert(PK::LPW == 64 && PK::KCAP <= 16, "far-field tiles: one walker per wavefront, <= 16 lines");
     const int K = R.K;
@@ -899,10 +950,18 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const typenam
         const LineRec& me = L.line[kq];
         const unsigned long long farmask = ff_classify<(int)sizeof(LineRec)>(Sx, K, lane, me.c, me.w8, me.w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
+        // near lines far wider than the tile join the interpolant (ff_wide_nodes); needs the lines' Taylor tables
+        unsigned long long widemask = 0ull;
+        int nwide = 0;
+        if constexpr (WIDE) {
+            widemask = wide_all & ~farmask;
+            nwide = __builtin_popcountll(widemask);
+            if ((widemask >> lane) & 1ull) Sx.widelist[__builtin_popcountll(widemask & ((1ull << lane) - 1ull))] = lane;
+        }
         // near lines: walk the set bits of the complement of the far mask (1-3 of 16 on the headline)
         // (VAMP_SKIP_*: timing-only builds of tools/variants.py -- the phase split in profiles/)
 #ifndef VAMP_SKIP_NEAR
-        for (unsigned long long near = ~farmask & ((1ull << K) - 1ull); near; near &= near - 1ull) {
+        for (unsigned long long near = ~(farmask | widemask) & ((1ull << K) - 1ull); near; near &= near - 1ull) {
             const int k = __builtin_ctzll(near);
             const LineRec ln = L.line[k];
             double X[T], H[T];
@@ -918,7 +977,16 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const typenam
         // load to its use and the wavefront sits through eight L2 round trips per tile
         double fi[T], wi[T];
 #ifndef VAMP_SKIP_FFNODES
-        if (nfar > 0) ff_coefficients<typename PK::Lds>(L, Sx, dct, lane, nfar, mid, half);
+        if (nfar + nwide > 0) {
+            double fs_wide = 0.0;
+            if constexpr (WIDE) {
+                if (nwide > 0) {
+                    __builtin_amdgcn_wave_barrier();          // (the wide list is in LDS)
+                    fs_wide = ff_wide_nodes<typename PK::Lds>(L, Sx, dct, tab, lane, nwide, mid, half);
+                }
+            }
+            ff_coefficients<typename PK::Lds>(L, Sx, dct, lane, nfar, mid, half, fs_wide);
+        }
 #endif
 #if VAMP_EARLY_LOADS
 #pragma unroll
@@ -929,7 +997,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const typenam
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifndef VAMP_SKIP_CLENSHAW
-        if (nfar > 0) ff_horner<double, T>(Sx, xi, mid, half, x_hi > x_lo, tau);
+        if (nfar + nwide > 0) ff_horner<double, T>(Sx, xi, mid, half, x_hi > x_lo, tau);
 #endif
         // the exp constants are read from LDS here, per tile: as literals they sit in ~30 SGPRs (or VGPRs) through
         // the whole loop, and the pointers and masks they displace are then reloaded from VGPR lanes in every tile
@@ -1240,9 +1308,17 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const typename P
             }
     } else {
         const double* x = px.x + R.pix_off; const double* f = px.f + R.pix_off; const double* wt = px.wt + R.pix_off;
-        if constexpr (VAMP_FARFIELD && PK::FF && MODE != VAMP_GAUSS3 && TPIX == 4)
-            sweep_range_ff<MODE, PK, TAB>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi, tab);
-        else if (TPIX > 1) sweep_range<MODE, PK, TPIX, TAB>(R, L, x, f, wt, lane, base0, full, stride, chi, tab);
+        if constexpr (VAMP_FARFIELD && PK::FF && MODE != VAMP_GAUSS3 && TPIX == 4) {
+            if constexpr (VAMP_WIDE_NODES && TAB) {
+                // lines far wider than a tile (stage_lines left their mask in the parameter block): none on a converged ensemble
+                const unsigned long long wide_all =
+                    (unsigned long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(L.theta[4 * PK::KCAP + 2]) & 0xffff));
+                if (wide_all) sweep_range_ff<MODE, PK, TAB, true>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi, tab, wide_all);
+                else sweep_range_ff<MODE, PK, TAB, false>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi, tab);
+            } else {
+                sweep_range_ff<MODE, PK, TAB>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi, tab);
+            }
+        } else if (TPIX > 1) sweep_range<MODE, PK, TPIX, TAB>(R, L, x, f, wt, lane, base0, full, stride, chi, tab);
         if constexpr (PK::TAIL || TPIX == 1)
             if (tail) {
                 const int from = TPIX > 1 ? full : 0;
