@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect PMC counters of the half-step kernel on the GPU box, one rocprofv3 pass per counter group
 # (never combined with tracing).  usage: tools/pmc.sh OUTDIR [program args...]
-#   default program: bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-chain
+#   default program: bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-chain --sustain-seconds 0
 #   e.g. tools/pmc.sh gpurun_out/pmc_c3 tools/bench_c3.py --steps 2 --warmup 1
 set -e
 OUT=$1; shift
-if [ $# -eq 0 ]; then set -- bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-chain; fi
+if [ $# -eq 0 ]; then set -- bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-chain --sustain-seconds 0; fi
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0

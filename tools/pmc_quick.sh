@@ -5,7 +5,7 @@ i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-chain "$@" > $OUT/p$i.log 2>&1 || echo "group $i failed"
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-chain --sustain-seconds 0 "$@" > $OUT/p$i.log 2>&1 || echo "group $i failed"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

@@ -25,6 +25,7 @@ ap.add_argument("--resident", type=int, default=1)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("--regions", type=int, default=1, help="copies of the region in the context (workgroup 0 is stamped)")
+ap.add_argument("--packing", type=int, default=0, help="force a launch shape (16: four walkers per wavefront; 64: one)")
 a = ap.parse_args()
 os.environ["VAMP_HIP_LIB"] = os.path.join(ROOT, "build", "variants", "lib_stamps.so")
 import vamp_amd                                                        # noqa: E402
@@ -45,6 +46,7 @@ for k in range(K):
     th[:, 4 * k + 3] = rng.uniform(2, 15, W)
 ctx = vamp_amd.HipContext(device=0, dtype=a.dtype)
 ctx.set_option("resident", a.resident)
+ctx.set_packing(a.packing)
 ctx.set_regions([x] * R, [flux] * R, [noise] * R, [K] * R, mode=vamp_amd.MODE_VOIGT4)
 ctx.sampler_init([th] * R, seed=5)
 ctx.run(50, store_chain=False)
@@ -68,7 +70,7 @@ for i0, i1 in zip(starts[:-1], starts[1:]):
     sums[key] = sums.get(key, 0) + int(clk[i1] - clk[i1 - 1])
     counts[key] = counts.get(key, 0) + 1
 half = np.diff(clk[starts]).mean() if starts.size > 1 else float("nan")
-out = {"config": f"P={x.size} K={K} W={W} regions={R} resident={a.resident} {a.dtype}", "stamps": int(n), "half_steps": int(starts.size),
+out = {"config": f"P={x.size} K={K} W={W} regions={R} resident={a.resident} {a.dtype} packing={a.packing}", "stamps": int(n), "half_steps": int(starts.size),
        "clocks_per_half_step_same_workgroup": float(half),
        "mean_clocks": {f"{k[0]}->{k[1]}": round(sums[k] / counts[k], 1) for k in sorted(sums)},
        "counts": {f"{k[0]}->{k[1]}": counts[k] for k in sorted(counts)}}

@@ -57,7 +57,7 @@ else:
         for n in names:
             env = dict(os.environ, VAMP_HIP_LIB=os.path.join(OUT, f"lib_{n}.so"))
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "1",
-                                  "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True)
+                                  "--no-cpu-baseline", "--sustain-seconds", "0"] + extra, env=env, capture_output=True, text=True)
             try:
                 j = json.loads(out.stdout.strip().splitlines()[-1])
                 res[n].append(j["roofline"]["avg_launch_ms"])

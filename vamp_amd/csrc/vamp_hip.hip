@@ -85,6 +85,12 @@ constexpr int KMAX = 16;                       // lines per region of the fast s
 constexpr int KMAX_ALL = VAMP_MAX_COMPONENTS;  // lines per region of the ABI: 17 .. 32 run the plain shape PackXL
 static_assert(KMAX_ALL >= KMAX && KMAX_ALL < 64, "lane k stages line k; one spare lane for sd");
 constexpr int WAVES_PER_BLOCK = 4;
+constexpr long long PACK_MIN_WALKERS = 16384;   // movers per launch from which the packed shapes fill the chip
+constexpr int RES_MAX_MOVERS = 128;             // movers per half-step (W / 2) a resident workgroup serves; also: "a small ensemble"
+#ifndef VAMP_RES_WAVES
+#define VAMP_RES_WAVES 8
+#endif
+constexpr int RES_MAX_WAVES = VAMP_RES_WAVES;   // compute wavefronts of a resident workgroup (+ the one that draws)
 constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
 constexpr int DMAX = 4 * KMAX_ALL + 1;
 // automatic choice of a 4-wave workgroup per walker (shared Taylor tables of the line cores, see
@@ -2126,8 +2132,6 @@ __global__ __launch_bounds__(PK::THREADS, (min_waves<F32, PK>())) void k_half_st
 // from the kernel, and an extra wavefront draws -- one mover per lane, the same Philox keys -- the NEXT half-step's draws
 // into an LDS double buffer while the others move.  The chain equals the launch-per-half-step chain bit for bit
 // (tests/test_gpu_parity.py::test_resident_step_loop_equals_launch_per_half_step).  No inter-workgroup communication.
-constexpr int RES_MAX_WAVES = 8;            // compute wavefronts of a resident workgroup (+ the one that draws)
-constexpr int RES_MAX_MOVERS = 128;         // movers per half-step (W / 2) a resident workgroup serves
 constexpr size_t RES_MAX_LDS = 150 * 1024;  // dynamic LDS of one resident workgroup (a workgroup may take all 160 KB of its CU)
 constexpr int RES_MAX_REGIONS = 256;        // automatic policy: at most one resident workgroup per compute unit
 struct alignas(16) ResDraws {
@@ -2181,6 +2185,7 @@ __global__ __launch_bounds__(64 * (RES_MAX_WAVES + 1), (min_waves<F32, PK>())) v
     if (drawer) draw_all(step0, 0, draws[0]);
     __syncthreads();
     long long kept = 0;
+    int until_keep = thin;                  // (a countdown: a 64-bit modulo per step is ~100 scalar instructions)
     for (long long it = 0; it < n_steps; ++it) {
         const unsigned step = step0 + (unsigned)it;
         for (int half = 0; half < 2; ++half) {
@@ -2201,7 +2206,9 @@ __global__ __launch_bounds__(64 * (RES_MAX_WAVES + 1), (min_waves<F32, PK>())) v
             __syncthreads();            // the movers' rows are in place (global, workgroup scope), the next draws are complete
             VAMP_STAMP(8);
         }
-        if ((it + 1) % thin == 0 && (chain || lchain)) {
+        const bool keep_now = --until_keep == 0;
+        if (keep_now) until_keep = thin;
+        if (keep_now && (chain || lchain)) {
             if (chain) {
                 const double* __restrict__ src = S.X + R.theta_off;
                 double* __restrict__ dst = chain + kept * total_theta + R.theta_off;
@@ -2484,17 +2491,27 @@ int ensure_part_events(vamp_ctx* c, int parts) {
     return 0;
 }
 
-// kernel shape of launch class `cl`: a property of the class alone (never of the ensemble's size, of this device's
-// share or piece of it, or of the entry point), so that a walker's log-posterior has the same bits everywhere.
-int class_shape(const vamp_ctx* c, const LaunchClass& cl, long long n_walkers, bool packable) {
-    (void)n_walkers;
+// kernel shape of launch class `cl` for an ensemble with `per_region` movers per region and half-step and `total` movers
+// per launch of the class -- UNSHARDED counts (W/2 of a walker-sharded single-region ensemble, whatever this device's share
+// or piece of it), so that a shard runs the shape, the same bits, the whole ensemble runs on one device.
+// The packed shapes (several walkers per wavefront: the fixed work of a wavefront shared) are the throughput shapes: launches
+// that fill the chip (>= PACK_MIN_WALKERS movers), and the small ensembles of model-selection ladders (<= RES_MAX_MOVERS
+// movers per region: tens of regions x tens of walkers, where they also feed the device-resident loop -- and single points:
+// vamp_lnprob, the MAP search).  In between -- config 2: one region, 4096 walkers -- a launch cannot fill the chip and is
+// bound by one wavefront's critical path: one walker per wavefront (14 us per half-step against 23 packed,
+// profiles/r04_c_small_ensembles.txt).  All callers of one context ask with the same counts.
+int class_shape(const vamp_ctx* c, const LaunchClass& cl, long long per_region, long long total, bool packable) {
     if (cl.kind == CK_XL) return SH_XL;
     if (cl.kind == CK_MID) return SH_MID;
-    // (round 4: whatever the ensemble's size -- a 32-walker ladder and a 65 536-walker ensemble of the same region run
-    //  the same arithmetic, and so do vamp_lnprob of one point, the MAP search and the device-resident step loop.
-    //  Sixteen lanes per walker for the one- and two-line regions of small launches was measured and dropped:
-    //  profiles/r04_c_small_ensembles.txt)
-    if ((cl.kind == CK_SMALL || cl.kind == CK_SMALL2) && packable) return cl.kind == CK_SMALL2 ? SH_SMALL2 : SH_SMALL;
+    if ((cl.kind == CK_SMALL || cl.kind == CK_SMALL2) && packable &&
+        (c->packing == 16 || per_region <= RES_MAX_MOVERS || total >= PACK_MIN_WALKERS)) {
+        // one- and two-line regions: eight lanes per walker is the throughput shape (six pixels per lane of a 44-pixel
+        // region: 14 800 clocks of sweep per half-step, in-kernel stamps); a small launch is bound by exactly that critical
+        // path, and sixteen lanes per walker (three pixels per lane: 8 300) still put an ensemble of <= 64 walkers into ONE
+        // round of a resident workgroup's eight wavefronts: 25 600 -> 19 200 clocks per half-step (profiles/r04_c_small_ensembles.txt)
+        if (cl.kind == CK_SMALL2 && c->packing != 16 && per_region <= RES_MAX_WAVES * PackSmall::SUBS && total < PACK_MIN_WALKERS) return SH_SMALL;
+        return cl.kind == CK_SMALL2 ? SH_SMALL2 : SH_SMALL;
+    }
     const bool split = cl.kind == CK_WIDE && (c->packing == 256 || (c->packing == 0 && c->min_tiles >= 2 * PARTS));
     if (split) return c->full_tiles ? SH_SPLIT_FULL : SH_SPLIT;
     return c->full_tiles ? SH_WIDE_FULL : SH_WIDE;
@@ -2605,7 +2622,7 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
         }
         S.region_list = cl.list_d;
         // (a shard or a piece of a single-region ensemble takes the shape of the WHOLE ensemble)
-        const int shape = class_shape(c, cl, (!ext && c->n_regions == 1) ? halfW : n, packable);
+        const int shape = class_shape(c, cl, ext ? n : halfW, (!ext && c->n_regions == 1) ? halfW : n, packable);
         unsigned grid = (unsigned)((n + shape_walkers_per_block(shape) - 1) / shape_walkers_per_block(shape));
         S.wpr = S.bpr = 0;
         S.n_cls_regions = (int)cl.regions.size();
@@ -2709,7 +2726,7 @@ bool resident_eligible(const vamp_ctx* c) {
     if (halfW > RES_MAX_MOVERS) return false;
     if (c->opt_resident == 1 && c->n_regions > RES_MAX_REGIONS) return false;
     for (const LaunchClass& cl : c->classes) {
-        const int shape = class_shape(c, cl, class_movers(c, cl), true);
+        const int shape = class_shape(c, cl, halfW, class_movers(c, cl), true);
         const int nw = resident_waves_for(c, shape, halfW);
         if (!vamp::plan::resident_class_ok(cl.kind, halfW, nw, (int)(shape_walkers_per_block(shape) / shape_waves(shape)), c->opt_resident == 1))
             return false;
@@ -2766,7 +2783,7 @@ int run_resident(vamp_ctx* c, long long n_steps, int thin, double* chain_dev, do
             HIP_TRY(hipStreamWaitEvent(st, c->ev_fork, 0));
         }
         S.region_list = cl.list_d;
-        const int shape = class_shape(c, cl, class_movers(c, cl), true);     // the shape launch_half runs this class in
+        const int shape = class_shape(c, cl, halfW, class_movers(c, cl), true);     // the shape launch_half runs this class in
         const int nw = resident_waves_for(c, shape, halfW);
         const dim3 grid((unsigned)cl.regions.size()), threads(64u * (unsigned)(nw + 1));
         if (c->f32)
@@ -3295,7 +3312,10 @@ int launch_lnprob(vamp_ctx* c, int region, long long W, const double* th_d, doub
     for (size_t ci = 0; ci < c->classes.size(); ++ci) {
         const LaunchClass& cl = c->classes[ci];
         if (!all && c->class_of[region] != (int)ci) continue;
-        const int shape = class_shape(c, cl, W, packable);
+        // W points per region are W/2 movers of a W-walker ensemble: the sampler's own initial log-posteriors, and a caller's
+        // walker checks, run the shape the ensemble will be stepped in
+        const long long per = (W + 1) / 2;
+        const int shape = class_shape(c, cl, per, all ? per * (long long)cl.regions.size() : per, packable);
         const long long per_block = shape_walkers_per_block(shape);
         const dim3 grid((unsigned)((W + per_block - 1) / per_block), all ? (unsigned)cl.regions.size() : 1u);
         const dim3 threads(shape_threads(shape));
@@ -3426,7 +3446,7 @@ int vamp_map_all(vamp_ctx* c, const double* theta0, const uint8_t* active, int64
         for (size_t ci = 0; ci < c->classes.size(); ++ci) {
             const LaunchClass& cl = c->classes[ci];
             // the shape vamp_lnprob runs a single point of this class in: the objective has the same bits
-            const int shape = class_shape(c, cl, 1, true);
+            const int shape = class_shape(c, cl, 1, 1, true);
             const dim3 grid((unsigned)cl.regions.size()), threads(shape_threads(shape));
             if (c->f32)
                 VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_map_search<true, M, PK>), grid, threads, 0, c->stream, c->regions_d, c->pix(),
