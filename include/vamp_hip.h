@@ -87,7 +87,8 @@ int vamp_ctx_set_option(vamp_ctx* ctx, const char* name, int64_t value);
  *        fp64, the line cores are read from per-line Taylor tables shared by the workgroup (long regions);
  *   16   four walkers per wavefront, <= 8 components per region (the short regions of real
  *        spectra; draws come from a one-thread-per-mover launch; automatic packing uses eight
- *        walkers per wavefront, 8 lanes each, for regions of one or two components);
+ *        walkers per wavefront, 8 lanes each, for regions of one or two components when the launch
+ *        fills the chip or the ensemble has 33 .. 128 movers per region);
  *   65   64 lanes + the walker's own Taylor tables (four lines' at a time), <= 8 components, no far
  *        field (the blended regions of real spectra: a few lines over a few hundred pixels; regions
  *        of more than 512 pixels fall back to per-pixel evaluation without tables);
@@ -95,10 +96,11 @@ int vamp_ctx_set_option(vamp_ctx* ctx, const char* name, int64_t value);
  *   evaluated per pixel (no far-field interpolant, no Taylor tables: those shapes hold 16 lines) -- the
  *   reference plans for such regions (vpspectrum.py:287-294: more than max_single_region_components = 15
  *   lines means fewer attempts and a laxer chi^2 limit, not a refusal), so they work; they are not fast.
- *   0    choose: contexts that look like a real spectrum (<= 8 components everywhere, mean region
- *        <= 128 pixels) are split into launch classes -- regions with >= 3 components over 96..512
- *        pixels run as 65, the rest as 16 (64 in launches of fewer than 16 384 walkers); otherwise
- *        256 when every region has >= 2048 pixels, else 64.
+ *   0    choose: contexts that look like a real spectrum (<= 8 components in every region of <= 16, mean
+ *        region <= 128 pixels) are split into launch classes -- regions with >= 3 components over 96..512
+ *        pixels run as 65, the rest as 16 when the launch fills the chip (>= 16 384 movers) or the ensemble is
+ *        small (<= 128 movers per region: model-selection ladders, single points, the MAP search, the
+ *        device-resident loop), as 64 in between; otherwise 256 when every region has >= 2048 pixels, else 64.
  * The choice never depends on how an ensemble is sharded, so a shard runs the arithmetic of the
  * whole ensemble.  Takes effect at the next vamp_set_regions.  fp64: all shapes agree to rounding.
  * fp32: 256 evaluates the line cores through single-precision Taylor rows instead of Humlicek's

@@ -1991,6 +1991,15 @@ __global__ __launch_bounds__(256) void k_draws(SamplerDev S, unsigned step, int 
 }
 
 constexpr int DRAW_INLINE = 0, DRAW_HOST = 1, DRAW_PRE = 2;      // where a mover's draws come from (k_half_step)
+#ifndef VAMP_UNIFORM_ACCEPT
+#define VAMP_UNIFORM_ACCEPT 1
+#endif
+__device__ __forceinline__ double uniform_double(double v) {      // a wave-uniform value, moved to scalar registers
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // One mover of a half-step: proposal q = c - (c - s) z into the walker's parameter block in LDS, its log-posterior,
 // the accept test and the state update.  `l` = lane inside the walker's group, `part` = the
@@ -2025,6 +2034,16 @@ __device__ __forceinline__ void stretch_move(const SamplerDev& S, const RegionDe
     asm volatile("" : "+v"(lnp_s));                          // keep the read up here
 #endif
     group_barrier<PK>();
+    if constexpr (PK::LPW == 64 && VAMP_UNIFORM_ACCEPT) {
+        // one walker per wavefront: the values the accept step needs after the sweep are the same in every lane -- hand
+        // them to the scalar registers, where they do not compete with the sweep for the 128 vector registers of the
+        // workgroup-per-walker shape (they were spilled around the sweep: 10 dwords per lane, 230 MB of scratch stores
+        // per launch of the headline)
+        lnp_s = uniform_double(lnp_s);
+        logu = uniform_double(logu);
+        z = uniform_double(z);
+        logz = uniform_double(logz);
+    }
     const double lnp_q = wave_lnprob<F32, MODE, PK>(R, L, Sx, dct, px, l, nullptr, part, red, tab);
     VAMP_STAMP(5);
     if (PK::SPLIT && part != 0) return;     // the group's first wave carries out the accept step

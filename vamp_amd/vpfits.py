@@ -29,6 +29,7 @@ There is no CPU fallback: constructing the model needs libvamp_hip.so and a GPU.
 from __future__ import annotations
 
 import datetime
+from collections.abc import Mapping
 
 import numpy as np
 
@@ -100,13 +101,36 @@ class _EnsembleMCMC:
         return _Trace(self._samples(name))
 
     def stats(self):
-        out = {}
-        for name, s in self._traces.items():
+        """name -> {'n', 'standard deviation', 'mean', 'quantiles', 'mc error'} as PyMC's ``MCMC.stats()``; an entry is
+        computed when it is read (the harvest of a spectrum reads two numbers per line, vpspectrum.py:400-412)."""
+        return _Stats(self)
+
+
+class _Stats(Mapping):
+    """``mcmc.stats()``: a read-only mapping over every trace name whose entries are computed on first access"""
+
+    def __init__(self, mcmc):
+        self._mcmc = mcmc
+        self._names = list(mcmc._names) + list(mcmc._derived)
+        self._done = {}
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+    def __getitem__(self, name):
+        if name not in self._done:
+            if name not in self._names:
+                raise KeyError(name)
+            s = self._mcmc._samples(name)
             q = np.percentile(s, [2.5, 25, 50, 75, 97.5])
-            out[name] = {"n": s.size, "standard deviation": float(np.std(s)), "mean": float(np.mean(s)),
-                         "quantiles": {2.5: q[0], 25: q[1], 50: q[2], 75: q[3], 97.5: q[4]},
-                         "mc error": float(np.std(s) / np.sqrt(max(1, s.size)))}
-        return out
+            sd = float(np.std(s))
+            self._done[name] = {"n": s.size, "standard deviation": sd, "mean": float(np.mean(s)),
+                                "quantiles": {2.5: q[0], 25: q[1], 50: q[2], 75: q[3], 97.5: q[4]},
+                                "mc error": sd / np.sqrt(max(1, s.size))}
+        return self._done[name]
 
 
 class _MAP:
