@@ -169,6 +169,38 @@ def test_vpfit_facade_on_the_host_abi_matches_oracle(cpu_lib, voigt, n):
     assert np.allclose(g.total.value, o.total.value, rtol=1e-9, atol=1e-300)
 
 
+@pytest.mark.parametrize("voigt", [False, True])
+def test_batched_find_bic_on_the_host_abi_matches_oracle(cpu_lib, voigt):
+    """vamp_amd.batched.find_bic_batched -- the three repeats of every region as 3 R regions of ONE context
+    (vpfits.py:417-428), array-based host side, fit objects built on demand -- through ctypes and the host ABI
+    against the same code on the oracle-backed context: the GPU test of tests/test_gpu_vpfit.py with the host
+    library in place of the HIP one.  Also the ladder on top of it (vpregion.py:42-91) end to end."""
+    import vamp_amd
+    from oracle_ctx import OracleContext
+    from vamp_amd.batched import BatchedRegionLadder, find_bic_batched
+    from vamp_amd.vpregion import VPregion
+    regions = [gv._hi_region(i) for i in range(3)]
+    ns = [1, 2, 1]
+    out = {}
+    for name, ctx in (("abi", vamp_amd.HipContext(lib=cpu_lib)), ("oracle", OracleContext())):
+        out[name] = find_bic_batched(ctx, regions, ns, voigt=voigt, nwalkers=32, iterations=20, thin=1, burn=5, seed=17)
+        assert ctx.n_regions == 9
+    for r, (g, o) in enumerate(zip(out["abi"], out["oracle"])):
+        assert len(set(g.bic_array)) == 3                                   # every repeat has a chain of its own
+        assert np.allclose(g.bic_array, o.bic_array, rtol=1e-9, atol=0), (r, g.bic_array, o.bic_array)
+        assert np.allclose(g.red_chi_array, o.red_chi_array, rtol=1e-9, atol=0)
+        fg, fo = g.detach().fit(), o.detach().fit()
+        assert np.allclose(fg._chain_dev, fo._chain_dev, rtol=1e-9, atol=1e-12) and fg.mcmc.DIC is None
+        assert np.isclose(fg.map.BIC, g.bic_array[-1]) and np.allclose(fg.total.value, fo.total.value, rtol=1e-9, atol=1e-300)
+        assert set(fg.mcmc.stats()) >= {"xexp_0", "est_centroid_0", "est_sigma_0", "sd"}
+    if not voigt:
+        regs = [VPregion(nu, f, n, voigt=False, nwalkers=32, seed=5) for nu, f, n in regions[1:]]
+        BatchedRegionLadder(regs, nwalkers=32, iterations=30, thin=1, burn=10, seed=3, verbose=False, ctx=vamp_amd.HipContext(lib=cpu_lib)).run()
+        for reg in regs:
+            assert 1 <= reg.n <= 6 and len(reg.fit.estimated_profiles) == reg.n and len(reg.fit.bic_array) == 3
+            assert reg.fit.total.value.shape == reg.flux_array.shape and np.isfinite(reg.fit.map.BIC)
+
+
 def test_host_plan_launch_classes_shards_and_grids(cpu_lib, cpu_ctx):
     """csrc/host_plan.hpp -- the launch-plan arithmetic of libvamp_hip.so (launch classes, shard and piece bounds,
     exchange buffer sizes, wavefronts per region of packed launches, the region -> XCD mapping, the resident loop's

@@ -40,7 +40,7 @@ def test_boundary_tests_under_asan_ubsan(asan_env):
     sized by VAMP_MAX_COMPONENTS), the launch / shard plan arithmetic shared with the product
     (csrc/host_plan.hpp): tests/test_cpu_boundary.py against the instrumented library"""
     sel = ("error_codes or pack_and_scatter or single_rank or philox or injected_draws or smallest_shapes "
-           "or map_all or exports_the_whole_header or lnprob_matches_golden or regions_of_more_than_16_lines "
+           "or map_all or exports_the_whole_header or lnprob_matches_golden or regions_of_more_than_16_lines or batched_find_bic "
            "or host_plan")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_cpu_boundary.py"), "-x", "-q",
                           "-p", "no:cacheprovider", "-k", sel], env=asan_env, capture_output=True, text=True, timeout=900, cwd=ROOT)
