@@ -22,6 +22,10 @@
 //   reduce  xor-shuffle tree over the wavefront (+ LDS across the workgroup); lane 0 owns the result.
 //   move    (sampler kernel) proposal q = c - (c - s) z is formed in LDS before `stage`, and the
 //           accept test / state update follow `reduce` in the same launch.
+// Kernels: k_lnprob / k_half_step (one launch per evaluation / per half-step of the stretch move), k_draws (the draws
+// of packed launches), k_run_resident (small ensembles: one workgroup per region runs the region's WHOLE step loop),
+// k_map_search (one workgroup per region runs its WHOLE Nelder-Mead MAP search, vpfits.py:352-358, 426), k_model,
+// k_scatter_rows (walker-sharded runs), k_wofz / k_line_records (test hooks).
 // No MFMA (nothing here is a contraction), no atomics, no inter-workgroup communication.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
