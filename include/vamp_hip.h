@@ -96,11 +96,12 @@ int vamp_ctx_set_option(vamp_ctx* ctx, const char* name, int64_t value);
  *   evaluated per pixel (no far-field interpolant, no Taylor tables: those shapes hold 16 lines) -- the
  *   reference plans for such regions (vpspectrum.py:287-294: more than max_single_region_components = 15
  *   lines means fewer attempts and a laxer chi^2 limit, not a refusal), so they work; they are not fast.
- *   0    choose: contexts that look like a real spectrum (<= 8 components in every region of <= 16, mean
- *        region <= 128 pixels) are split into launch classes -- regions with >= 3 components over 96..512
- *        pixels run as 65, the rest as 16 when the launch fills the chip (>= 16 384 movers) or the ensemble is
- *        small (<= 128 movers per region: model-selection ladders, single points, the MAP search, the
- *        device-resident loop), as 64 in between; otherwise 256 when every region has >= 2048 pixels, else 64.
+ *   0    choose: contexts that look like a real spectrum (the regions of <= 16 components are <= 128 pixels
+ *        long on average) are split into launch classes -- regions with 3..8 components over 96..512 pixels
+ *        run as 65, regions of 9..16 components as 64, the rest as 16 when the launch fills the chip
+ *        (>= 16 384 movers) or the ensemble is small (<= 128 movers per region: model-selection ladders, single
+ *        points, the MAP search, the device-resident loop) and as 64 in between; otherwise 256 when every region
+ *        has >= 2048 pixels, else 64.
  * The choice never depends on how an ensemble is sharded, so a shard runs the arithmetic of the
  * whole ensemble.  Takes effect at the next vamp_set_regions.  fp64: all shapes agree to rounding.
  * fp32: 256 evaluates the line cores through single-precision Taylor rows instead of Humlicek's
@@ -134,7 +135,8 @@ int vamp_set_region_ids(vamp_ctx* ctx, const int32_t* ids);
 /* Launch class of a region: 0 short (four walkers per wavefront), 1 blend (a wavefront and per-walker Taylor tables
  * per walker), 2 wide (one walker per wavefront or per 4-wavefront workgroup), 3 short with one or two components
  * (eight walkers per wavefront), 4 more than 16 components -- and the number of classes of the context (one launch
- * per class and half-step).  Diagnostics: which kernels a context will run; see vamp_ctx_set_packing.  Either
+ * per class and half-step).  This is the partition of large ensembles; for small ones (<= 128 movers per region)
+ * classes 0 and 3 are one class, four walkers per wavefront: a launch less per half-step.  Diagnostics: which kernels a context will run; see vamp_ctx_set_packing.  Either
  * output may be NULL. */
 int vamp_region_class(vamp_ctx* ctx, int region, int* kind, int* n_classes);
 /* number of sampled dimensions of a region (q*K, +1 with sample_sd) */

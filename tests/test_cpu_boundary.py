@@ -219,6 +219,11 @@ def test_host_plan_launch_classes_shards_and_grids(cpu_lib, cpu_ctx):
     sub = lambda seq: [seq[i] for i in short]
     cpu_ctx.set_regions(sub(xs), [np.ones(P) for P, _ in sub(shapes)], [np.ones(P) for P, _ in sub(shapes)], [K for _, K in sub(shapes)], mode=0)
     assert cpu_ctx.region_classes() == ([3, 0, 0, 0, 0, 0, 0, 3] + [3] * 8, 2)          # Gaussian components: no tables, no blend class
+    # a few regions of 9 .. 16 lines take the one-walker-per-wavefront class on their own
+    mix = [(40, 1)] * 6 + [(60, 9), (200, 16), (120, 4)]
+    cpu_ctx.set_regions([np.arange(P, dtype=np.float64) for P, _ in mix], [np.ones(P) for P, _ in mix], [np.ones(P) for P, _ in mix],
+                        [K for _, K in mix], mode=1)
+    assert cpu_ctx.region_classes() == ([3] * 6 + [2, 2, 1], 3)
     long_x = [np.arange(2048, dtype=np.float64), np.arange(4096, dtype=np.float64)]
     cpu_ctx.set_regions(long_x, [np.ones(x.size) for x in long_x], [np.ones(x.size) for x in long_x], [16, 3], mode=1)
     assert cpu_ctx.region_classes() == ([2, 2], 1)

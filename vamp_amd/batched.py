@@ -142,9 +142,13 @@ def find_bic_batched(ctx, regions, ns, voigt=False, nwalkers=64, iterations=3000
             X0[j][bad] = fallback[j][bad]                        # a poor start cannot trap the ensemble
         X0[j][0] = centre[j]
     ctx.sampler_init(X0, seed=(int(seed) * 2654435761 + 0x9E37) & (2 ** 64 - 1), a=2.0, split_block=hb.default_split_block(W))
+    import os
+    import time
+    t_run = time.perf_counter()
     if burn > 0:
         ctx.run(burn, store_chain=False)
     chain2d, lnp2d, nacc1d, seconds = ctx.run_flat(keep, thin=thin)
+    t_run = time.perf_counter() - t_run
     n_keep = chain2d.shape[0]
     offs = np.concatenate([[0], np.cumsum([W * d for d in ctx.ndims])])
     chains = [chain2d[:, offs[j]:offs[j + 1]].reshape(n_keep, W, ctx.ndims[j]) for j in range(J)]
@@ -152,7 +156,14 @@ def find_bic_batched(ctx, regions, ns, voigt=False, nwalkers=64, iterations=3000
     # MAP polish of every (region, repeat) together, started from its best posterior sample (VPfit._map_start)
     flat_best = lnp3.transpose(1, 0, 2).reshape(J, n_keep * W).argmax(axis=1)
     starts = [chains[j][flat_best[j] // W, flat_best[j] % W] for j in range(J)]
-    best, lnp_best, ssum_best, _ = ctx.map_all(starts, iterlim=iterations, tol=1e-3)
+    t_map = time.perf_counter()
+    best, lnp_best, ssum_best, its = ctx.map_all(starts, iterlim=iterations, tol=1e-3)
+    t_map = time.perf_counter() - t_map
+    if os.environ.get("VAMP_FIT_TIMING"):       # developer knob: where a rung's time goes
+        kinds = ctx.region_classes()[0] if hasattr(ctx, "region_classes") else []
+        print("vamp_rung regions=%d (x%d repeats) W=%d steps=%d run=%.1f ms (%.1f us per half-step) map=%.1f ms (max %d iterations) classes=%s"
+              % (R, REPEATS, W, burn + keep, t_run * 1e3, t_run * 1e6 / (2 * (burn + keep)), t_map * 1e3, int(np.max(its)),
+                 {k: kinds.count(k) for k in sorted(set(kinds))}), flush=True)
     taus, fluxes = ctx.model_all(best)
     # PyMC 2.3's information criteria at the optimum (vamp_amd.vpfits._MAP): lnL of the observed flux with the free precision
     sd = np.array([b[-1] for b in best])

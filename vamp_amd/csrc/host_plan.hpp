@@ -51,8 +51,12 @@ struct ClassPlan {
 
 // packing: 0 automatic, 16 / 64 / 65 / 256 forced (vamp_ctx_set_packing).  gauss: Gaussian components (no tables).
 // tables_f32: fp32 contexts have single-precision Taylor rows for their blends.  Returns "" or an error message.
+// merged: the partition for SMALL ENSEMBLES (<= 128 movers per region: model-selection ladders, single points, the MAP
+// search).  There a half-step is bound by its launches, not by its arithmetic -- every class is a launch of its own,
+// ~15 us each on one stream, where the whole half-step of 1218 short regions is ~25 us of work -- so all regions of
+// <= 8 lines that are not blends form ONE class (four walkers per wavefront serve any of them).
 inline std::string plan_classes(const std::vector<RegionShape>& R, int packing, bool gauss, bool f32, bool tables_f32, ClassPlan& out,
-                                const Limits& lim = Limits()) {
+                                const Limits& lim = Limits(), bool merged = false) {
     const int n = (int)R.size();
     int kmax = 0, n_std = 0;
     long long pix_std = 0;
@@ -72,23 +76,28 @@ inline std::string plan_classes(const std::vector<RegionShape>& R, int packing, 
     const double mean_p = n_std ? (double)pix_std / n_std : 0.0;
     if ((packing == 16 || packing == 65) && (kmax > lim.small_kcap || n_std < n))
         return "packings 16 and 65 support at most 8 components per region";
-    // judged over the regions of <= kmax lines only: a region of 17+ lines has its own class whatever the others run
-    out.spectrum_like = packing == 0 && n_std > 0 && kmax <= lim.small_kcap && mean_p <= lim.mean_p_max;
-    std::vector<int> cls[4];
+    // A context "looks like a spectrum" when its regions of <= kmax lines are short on average: judged over those only (a
+    // region of 17+ lines has its own class whatever the others run), and WITHOUT a limit on their line counts: a model-
+    // selection ladder grows a few regions past 8 lines, and those few take the one-walker-per-wavefront class on their
+    // own instead of dragging hundreds of one- and two-line regions there (round 4: the second rung of the q1422 ladder,
+    // 1218 regions, one of them with 9 lines: 94 us per half-step, all of it in the wide class).
+    out.spectrum_like = packing == 0 && n_std > 0 && mean_p <= lim.mean_p_max;
+    std::vector<int> cls[5];
     const int kind0 = packing == 16 ? CK_SMALL : packing == 65 ? CK_MID : out.spectrum_like ? CK_SMALL : CK_WIDE;
-    const int kinds[4] = {kind0, CK_MID, CK_SMALL2, CK_XL};
+    const int kinds[5] = {kind0, CK_MID, CK_SMALL2, CK_XL, CK_WIDE};
     for (int r = 0; r < n; ++r) {
         int k = 0;
         if (R[r].K > lim.kmax) {
             k = 3;
         } else if (out.spectrum_like) {
-            if (R[r].K >= lim.mid_min_k && R[r].P >= lim.mid_min_p && R[r].P <= lim.blend_max_p && !gauss && (!f32 || tables_f32)) k = 1;
-            else if (R[r].K <= lim.small2_kcap) k = 2;
+            if (R[r].K > lim.small_kcap) k = 4;           // 9 .. 16 lines: one walker per wavefront
+            else if (R[r].K >= lim.mid_min_k && R[r].P >= lim.mid_min_p && R[r].P <= lim.blend_max_p && !gauss && (!f32 || tables_f32)) k = 1;
+            else if (R[r].K <= lim.small2_kcap && !merged) k = 2;
         }
         cls[k].push_back(r);
     }
     out.class_of.assign(n, 0);
-    for (int k : {1, 2, 0, 3})
+    for (int k : {1, 2, 0, 4, 3})
         if (!cls[k].empty()) {
             for (int r : cls[k]) out.class_of[r] = (int)out.kind.size();
             out.kind.push_back(kinds[k]);

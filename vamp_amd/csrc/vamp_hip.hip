@@ -2356,6 +2356,10 @@ struct vamp_ctx {
     bool full_tiles = false;   // every region's pixel count is a multiple of 64 * TPIX
     std::vector<LaunchClass> classes;      // partition of the regions by kernel shape (vamp_set_regions)
     std::vector<int> class_of;             // region -> index into classes
+    // the partition for SMALL ensembles (<= RES_MAX_MOVERS movers per region): the short-region classes merged into one
+    // (vamp::plan::plan_classes, merged) -- a class is a launch per half-step, and there launches are what a half-step costs
+    std::vector<LaunchClass> classes_small;
+    std::vector<int> class_of_small;
     // draws of packed launches (k_draws), grown on demand
     int *dr_ws = nullptr, *dr_wc = nullptr;
     double *dr_z = nullptr, *dr_lu = nullptr, *dr_lz = nullptr;
@@ -2436,10 +2440,13 @@ int free_regions(vamp_ctx* c) {
     for (void* p : {(void*)c->regions_d, (void*)c->x_d, (void*)c->f_d, (void*)c->wt_d, (void*)c->xf_d, (void*)c->ff_d,
                     (void*)c->wtf_d})
         if (p) (void)hipFree(p);
-    for (LaunchClass& cl : c->classes)
-        if (cl.list_d) (void)hipFree(cl.list_d);
-    c->classes.clear();
+    for (std::vector<LaunchClass>* part : {&c->classes, &c->classes_small}) {
+        for (LaunchClass& cl : *part)
+            if (cl.list_d) (void)hipFree(cl.list_d);
+        part->clear();
+    }
     c->class_of.clear();
+    c->class_of_small.clear();
     c->regions_d = nullptr;
     c->x_d = c->f_d = c->wt_d = nullptr;
     c->xf_d = c->ff_d = c->wtf_d = nullptr;
@@ -2523,16 +2530,25 @@ int ensure_part_events(vamp_ctx* c, int parts) {
 // vamp_lnprob, the MAP search).  In between -- config 2: one region, 4096 walkers -- a launch cannot fill the chip and is
 // bound by one wavefront's critical path: one walker per wavefront (14 us per half-step against 23 packed,
 // profiles/r04_c_small_ensembles.txt).  All callers of one context ask with the same counts.
+// the launch classes an ensemble of `per_region` movers per region and half-step runs in (callers of one context ask with
+// the same count: the sampler and the resident loop with W / 2, vamp_lnprob(_all) of W points with W / 2, the MAP search with 1)
+inline bool small_ensemble(long long per_region) { return per_region <= RES_MAX_MOVERS; }
+const std::vector<LaunchClass>& partition_for(const vamp_ctx* c, long long per_region) {
+    return small_ensemble(per_region) ? c->classes_small : c->classes;
+}
+const std::vector<int>& class_of_for(const vamp_ctx* c, long long per_region) {
+    return small_ensemble(per_region) ? c->class_of_small : c->class_of;
+}
 int class_shape(const vamp_ctx* c, const LaunchClass& cl, long long per_region, long long total, bool packable) {
     if (cl.kind == CK_XL) return SH_XL;
     if (cl.kind == CK_MID) return SH_MID;
     if ((cl.kind == CK_SMALL || cl.kind == CK_SMALL2) && packable &&
         (c->packing == 16 || per_region <= RES_MAX_MOVERS || total >= PACK_MIN_WALKERS)) {
         // one- and two-line regions: eight lanes per walker is the throughput shape (six pixels per lane of a 44-pixel
-        // region: 14 800 clocks of sweep per half-step, in-kernel stamps); a small launch is bound by exactly that critical
-        // path, and sixteen lanes per walker (three pixels per lane: 8 300) still put an ensemble of <= 64 walkers into ONE
-        // round of a resident workgroup's eight wavefronts: 25 600 -> 19 200 clocks per half-step (profiles/r04_c_small_ensembles.txt)
-        if (cl.kind == CK_SMALL2 && c->packing != 16 && per_region <= RES_MAX_WAVES * PackSmall::SUBS && total < PACK_MIN_WALKERS) return SH_SMALL;
+        // region: 14 800 clocks of sweep per half-step, in-kernel stamps); a small ensemble is bound by exactly that critical
+        // path and runs sixteen lanes per walker (three pixels per lane: 8 300; profiles/r04_c_small_ensembles.txt) -- as
+        // part of the merged short-region class
+        // (small ensembles never see CK_SMALL2: their partition has the short-region classes merged, partition_for)
         return cl.kind == CK_SMALL2 ? SH_SMALL2 : SH_SMALL;
     }
     const bool split = cl.kind == CK_WIDE && (c->packing == 256 || (c->packing == 0 && c->min_tiles >= 2 * PARTS));
@@ -2603,8 +2619,13 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     // several walkers per wavefront need every wavefront inside one region: trivially so with one region, else the
     // wavefronts are dealt per region (SamplerDev::wpr); host-supplied draws run one walker per wavefront
     const bool packable = !ext;
-    const size_t ncls = c->classes.size();
-    const bool fork = !ext && ncls > 1 && c->concurrent_classes;
+    const std::vector<LaunchClass>& classes = partition_for(c, halfW);
+    const std::vector<int>& class_of = class_of_for(c, halfW);
+    const size_t ncls = classes.size();
+    // the classes of a half-step on forked streams fill each other's stalls when the launches are big (config 3: 4.85 ->
+    // 4.20 ms); for the small ensembles of a ladder the event traffic of fork and join costs more than it hides
+    // (q1422 ladder, first rung: 73 -> 57 us per half-step without it)
+    const bool fork = !ext && ncls > 1 && c->concurrent_classes && c->total_walkers / 2 >= PACK_MIN_WALKERS * 4;
     if (fork) {
         while (c->cls_stream.size() < ncls - 1) {
             hipStream_t st;
@@ -2620,11 +2641,11 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
     // draws of the packed classes: one slice of the buffers per class (the classes may overlap in time)
     long long draw_total = 0;
     if (!ext)
-        for (const LaunchClass& cl : c->classes) draw_total += (c->n_regions == 1) ? c->total_walkers : (long long)cl.regions.size() * halfW;
+        for (const LaunchClass& cl : classes) draw_total += (c->n_regions == 1) ? c->total_walkers : (long long)cl.regions.size() * halfW;
     long long draw_off = 0;
     for (size_t ci = 0; ci < ncls; ++ci) {
-        const LaunchClass& cl = c->classes[ci];
-        if (ext && c->class_of[ext_region] != (int)ci) continue;
+        const LaunchClass& cl = classes[ci];
+        if (ext && class_of[ext_region] != (int)ci) continue;
         long long n;
         if (ext) {
             n = ext_n;
@@ -2667,10 +2688,11 @@ int launch_half(vamp_ctx* c, int half, bool ext, int ext_region, long long ext_n
             else
                 VAMP_FOR_MODE_PK(c->mode, shape, hipLaunchKernelGGL((k_half_step<false, DRAW_HOST, M, PK>), dim3(grid), threads, 0, st, S, px, step,
                                                           half, ext_region, ext_n, c->ext_act_d, c->ext_par_d, c->ext_z_d, c->ext_lu_d, nd));
-        } else if (shape == SH_SMALL || shape == SH_SMALL2 || (shape == SH_MID && VAMP_MID_PREDRAW)) {
+        } else if (!small_ensemble(halfW) && (shape == SH_SMALL || shape == SH_SMALL2 || (shape == SH_MID && VAMP_MID_PREDRAW))) {
             // four walkers per wavefront (or a walker per wavefront at ~1.7 wavefronts per SIMD, where
             // ~1000 scalar instructions of draws are exposed latency): draws in their own
-            // one-thread-per-mover launch
+            // one-thread-per-mover launch -- for ensembles that fill the chip; a small ensemble's half-step is bound by
+            // its launches, and draws in the kernel are one launch less (the same draws: same keys, same functions)
             int rc = ensure_draw_buffers(c, draw_total);
             if (rc) return rc;
             int *d_ws = c->dr_ws + draw_off, *d_wc = c->dr_wc + draw_off;
@@ -2748,7 +2770,7 @@ bool resident_eligible(const vamp_ctx* c) {
     const long long halfW = c->W / 2;
     if (halfW > RES_MAX_MOVERS) return false;
     if (c->opt_resident == 1 && c->n_regions > RES_MAX_REGIONS) return false;
-    for (const LaunchClass& cl : c->classes) {
+    for (const LaunchClass& cl : partition_for(c, halfW)) {
         const int shape = class_shape(c, cl, halfW, class_movers(c, cl), true);
         const int nw = resident_waves_for(c, shape, halfW);
         if (!vamp::plan::resident_class_ok(cl.kind, halfW, nw, (int)(shape_walkers_per_block(shape) / shape_waves(shape)), c->opt_resident == 1))
@@ -2770,7 +2792,8 @@ int run_resident(vamp_ctx* c, long long n_steps, int thin, double* chain_dev, do
     S.lnp = c->lnp_d;
     S.n_accept = c->nacc_d;
     const long long halfW = c->W / 2;
-    const size_t ncls = c->classes.size();
+    const std::vector<LaunchClass>& classes = partition_for(c, halfW);
+    const size_t ncls = classes.size();
     const bool fork = ncls > 1 && c->concurrent_classes;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
@@ -2799,7 +2822,7 @@ int run_resident(vamp_ctx* c, long long n_steps, int thin, double* chain_dev, do
     }
     const PixPtrs px = c->pix();
     for (size_t ci = 0; ci < ncls; ++ci) {
-        const LaunchClass& cl = c->classes[ci];
+        const LaunchClass& cl = classes[ci];
         hipStream_t st = c->stream;
         if (fork && ci > 0) {
             st = c->cls_stream[ci - 1];
@@ -3279,17 +3302,24 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
         c->full_tiles = cp.full_tiles;
         c->min_tiles = cp.min_tiles;
         c->class_of = cp.class_of;
-        for (size_t k = 0; k < cp.kind.size(); ++k) {
-            LaunchClass cl;
-            cl.kind = cp.kind[k];
-            cl.regions = cp.regions[k];
-            c->classes.push_back(cl);
-        }
-        if (c->classes.size() > 1)
-            for (LaunchClass& cl : c->classes) {
-                HIP_TRY(hipMalloc(&cl.list_d, cl.regions.size() * sizeof(int)));
-                HIP_TRY(hipMemcpy(cl.list_d, cl.regions.data(), cl.regions.size() * sizeof(int), hipMemcpyHostToDevice));
+        vamp::plan::ClassPlan cs;          // the partition of small ensembles: short-region classes merged
+        (void)vamp::plan::plan_classes(shp, c->packing, mode == VAMP_GAUSS3, c->f32, VAMP_F32_TABLES != 0, cs, lim, true);
+        c->class_of_small = cs.class_of;
+        for (int which = 0; which < 2; ++which) {
+            const vamp::plan::ClassPlan& pl = which ? cs : cp;
+            std::vector<LaunchClass>& part = which ? c->classes_small : c->classes;
+            for (size_t k = 0; k < pl.kind.size(); ++k) {
+                LaunchClass cl;
+                cl.kind = pl.kind[k];
+                cl.regions = pl.regions[k];
+                part.push_back(cl);
             }
+            if (part.size() > 1)
+                for (LaunchClass& cl : part) {
+                    HIP_TRY(hipMalloc(&cl.list_d, cl.regions.size() * sizeof(int)));
+                    HIP_TRY(hipMemcpy(cl.list_d, cl.regions.data(), cl.regions.size() * sizeof(int), hipMemcpyHostToDevice));
+                }
+        }
     }
     c->regions_h = R;
     c->mode = mode;
@@ -3332,12 +3362,14 @@ namespace {
 int launch_lnprob(vamp_ctx* c, int region, long long W, const double* th_d, double* lp_d, double* ch_d) {
     const bool all = region < 0;
     const bool packable = true;      // one region per block row: every wave lies inside one region
-    for (size_t ci = 0; ci < c->classes.size(); ++ci) {
-        const LaunchClass& cl = c->classes[ci];
-        if (!all && c->class_of[region] != (int)ci) continue;
-        // W points per region are W/2 movers of a W-walker ensemble: the sampler's own initial log-posteriors, and a caller's
-        // walker checks, run the shape the ensemble will be stepped in
-        const long long per = (W + 1) / 2;
+    // W points per region are W/2 movers of a W-walker ensemble: the sampler's own initial log-posteriors, and a caller's
+    // walker checks, run the classes and shapes the ensemble will be stepped in
+    const long long per = (W + 1) / 2;
+    const std::vector<LaunchClass>& classes = partition_for(c, per);
+    const std::vector<int>& class_of = class_of_for(c, per);
+    for (size_t ci = 0; ci < classes.size(); ++ci) {
+        const LaunchClass& cl = classes[ci];
+        if (!all && class_of[region] != (int)ci) continue;
         const int shape = class_shape(c, cl, per, all ? per * (long long)cl.regions.size() : per, packable);
         const long long per_block = shape_walkers_per_block(shape);
         const dim3 grid((unsigned)((W + per_block - 1) / per_block), all ? (unsigned)cl.regions.size() : 1u);
@@ -3466,8 +3498,9 @@ int vamp_map_all(vamp_ctx* c, const double* theta0, const uint8_t* active, int64
         HIP_TRY(hipMemcpyAsync(c->map_th_d, theta0, nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
         if (active) HIP_TRY(hipMemcpyAsync(c->map_act_d, active, nr, hipMemcpyHostToDevice, c->stream));
         const unsigned char* act_d = active ? c->map_act_d : nullptr;
-        for (size_t ci = 0; ci < c->classes.size(); ++ci) {
-            const LaunchClass& cl = c->classes[ci];
+        const std::vector<LaunchClass>& classes = partition_for(c, 1);
+        for (size_t ci = 0; ci < classes.size(); ++ci) {
+            const LaunchClass& cl = classes[ci];
             // the shape vamp_lnprob runs a single point of this class in: the objective has the same bits
             const int shape = class_shape(c, cl, 1, 1, true);
             const dim3 grid((unsigned)cl.regions.size()), threads(shape_threads(shape));
