@@ -24,6 +24,9 @@ them, the ladder leaves them ``None``.
 """
 from __future__ import annotations
 
+import os
+import time
+
 import numpy as np
 
 from . import hip_backend as hb
@@ -142,8 +145,6 @@ def find_bic_batched(ctx, regions, ns, voigt=False, nwalkers=64, iterations=3000
             X0[j][bad] = fallback[j][bad]                        # a poor start cannot trap the ensemble
         X0[j][0] = centre[j]
     ctx.sampler_init(X0, seed=(int(seed) * 2654435761 + 0x9E37) & (2 ** 64 - 1), a=2.0, split_block=hb.default_split_block(W))
-    import os
-    import time
     t_run = time.perf_counter()
     if burn > 0:
         ctx.run(burn, store_chain=False)

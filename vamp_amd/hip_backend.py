@@ -404,8 +404,7 @@ class HipContext:
         """Returns dict(chain, lnprob, n_accept, seconds); chain/lnprob are arrays for a single
         region ([n_keep, W, D] / [n_keep, W]) or lists of such arrays."""
         chain, lchain, nacc, seconds = self.run_flat(n_steps, thin=thin, store_chain=store_chain)
-        sec = C.c_double(seconds)
-        res = {"seconds": sec.value, "n_accept": nacc if self.n_regions == 1 else self._split(nacc, True)}
+        res = {"seconds": seconds, "n_accept": nacc if self.n_regions == 1 else self._split(nacc, True)}
         if store_chain:
             ch, lc = self._split(chain, False), self._split(lchain, True)
             res["chain"] = ch[0] if self.n_regions == 1 else ch
