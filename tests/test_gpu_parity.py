@@ -1176,10 +1176,11 @@ def test_long_region_symmetries(hip_ctx):
 
 @pytest.mark.parametrize("script,args", [("soak_long_regions.py", ["24"]), ("soak_long_regions.py", ["24", "f32"]),
                                          ("soak_short_regions.py", ["10"]), ("soak_short_regions.py", ["10", "f32"]),
-                                         ("soak_sampler.py", ["8"])])
+                                         ("soak_sampler.py", ["8"]), ("soak_resident_map.py", ["24"])])
 def test_soaks_in_short(script, args):
     """The developer soaks (tests/soak_*.py: random long and short regions with widths and dampings over decades,
-    every packing, fp64 at 1e-9 and fp32 at 1e-3 against the oracle) over a few seeds on every GPU test run; the
+    every packing, fp64 at 1e-9 and fp32 at 1e-3 against the oracle; the resident step loop and the device MAP search
+    against their launch-per-step forms bit for bit on random contexts) over a few seeds on every GPU test run; the
     fp32 long-region soak is what found the W4 region II clamp in round 3."""
     import os
     import subprocess
