@@ -454,6 +454,8 @@ class VPfit():
                  iterations=3000, thin=15, burn=300, thorough=False):
         """Three independent {model, MCMC, MAP} repeats; collects map.BIC and the reduced chi^2 of
         the MAP model (vpfits.py:398-429)."""
+        if not thorough and self.noise is None:
+            return self._find_bic_folded(frequency_array, flux_array, n, noise_array, freedom, voigt, iterations, thin, burn)
         self.bic_array = []
         self.red_chi_array = []
         for i in range(3):
@@ -470,6 +472,30 @@ class VPfit():
             self.bic_array.append(self.map.BIC)
             self.red_chi_array.append(self.ReducedChisquared(flux_array, self.total.value, noise_array, freedom))
         return
+
+    def _find_bic_folded(self, frequency_array, flux_array, n, noise_array, freedom, voigt, iterations, thin, burn):
+        """The three repeats of ``find_bic`` as THREE regions of one context (vamp_amd.batched.find_bic_batched with one
+        region): one ensemble run, one MAP launch and one model launch instead of three of each -- a third of the device
+        calls of a path that is bound by them.  Every repeat has a chain of its own (its region index keys the draws);
+        ``self`` ends as the last repeat's fit, as in the reference (vpfits.py:417-428), bound to a context that holds
+        this one region again, so every method keeps working on it."""
+        from .batched import find_bic_batched            # (batched imports this module)
+        self._seed = (int(self._seed) * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
+        if self._ctx is None:
+            self._ctx = hb.HipContext(device=self.device, dtype=self.dtype)
+        ctx, mine = self._ctx, {k: self.__dict__[k] for k in ("noise", "std_deviation", "verbose", "device", "dtype", "_seed", "nwalkers")
+                                if k in self.__dict__}
+        res = find_bic_batched(ctx, [(np.asarray(frequency_array, dtype=np.float64), np.asarray(flux_array, dtype=np.float64), noise_array)],
+                               [int(n)], voigt=voigt, nwalkers=self.nwalkers, iterations=iterations, thin=thin, burn=burn,
+                               seed=int(self._seed) & 0x7FFFFFFFFFFFFFFF, freedoms=[freedom], score_chains=True)[0]
+        last = res.detach().fit()
+        self.__dict__.update(last.__dict__)
+        self.__dict__.update(mine)
+        self.map._fit = self.mcmc._fit = self
+        self.bic_array, self.red_chi_array = list(res.bic_array), list(res.red_chi_array)
+        # the context held the three repeats; this fit is a fit of ONE region again
+        self._region, self._shared_ctx = 0, False
+        ctx.set_regions(self._x, self._flux, np.ones_like(self._flux), self._n, mode=self._mode, sample_sd=True)
 
     def chain_covariance(self, n, voigt=False):
         """Per-component 3x3 covariance of (amplitude, sigma, centroid) samples (vpfits.py:432-456)."""

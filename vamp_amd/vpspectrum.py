@@ -276,7 +276,11 @@ class VPspectrum():
             if self.verbose:
                 print('Reduced chi squared is {:.2f}'.format(chi))
             if best_fit is None or chi < best_chi:
+                if best_fit is not None:
+                    region._release(best_fit)            # (the device context of a fit that is dropped)
                 best_chi, best_fit = chi, region.fit
+            else:
+                region._release(region.fit)
             if best_chi < limit:
                 break
         return best_chi, best_fit
