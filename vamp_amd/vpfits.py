@@ -453,7 +453,9 @@ class VPfit():
     def find_bic(self, frequency_array, flux_array, n, noise_array, freedom, voigt=False,
                  iterations=3000, thin=15, burn=300, thorough=False):
         """Three independent {model, MCMC, MAP} repeats; collects map.BIC and the reduced chi^2 of
-        the MAP model (vpfits.py:398-429)."""
+        the MAP model (vpfits.py:398-429).  The reference's form of the call (VPfit() without noise, thorough=False:
+        vpregion.py:59) runs the three repeats as three regions of one context (_find_bic_folded); a fit with known
+        noise, or thorough=True, runs them one after the other as written there."""
         if not thorough and self.noise is None:
             return self._find_bic_folded(frequency_array, flux_array, n, noise_array, freedom, voigt, iterations, thin, burn)
         self.bic_array = []
