@@ -966,6 +966,54 @@ def test_full_size_dispersed_walkers_match_oracle(hip_ctx, grid):
     assert np.allclose(res["lnprob"][-1][fin], lchain[-1][fin], rtol=1e-9, atol=1e-9), grid
 
 
+@pytest.mark.parametrize("case", ["threshold", "prior"])
+def test_lines_wider_than_a_tile_match_oracle(hip_ctx, case):
+    """Round 4: near lines far wider than a tile are evaluated at the tile's 16 Chebyshev nodes and reach the pixels
+    through the tile's interpolant (ff_wide_nodes) when half a tile is at most 1 in the line's own z, i.e. from
+    G_fwhm ~ 213 px on a unit grid.  Headline size (P = 16 384, K = 16): (threshold) widths within 10 % above the
+    switch -- where the interpolation error is largest -- mixed with widths just below it (evaluated per pixel), dampings
+    from 1e-6 to 300 px, optical depths up to ~50; (prior) every parameter drawn from the priors of vpfits.py:283-297 as
+    bench.py --ensemble prior does: every line wide, nothing far.  Log-posterior against the oracle to 1e-9, and one
+    stretch step against the oracle's sampler."""
+    if hip_ctx.packing_request in (16, 65):
+        pytest.skip("long regions: one walker per wavefront or workgroup")
+    rng = np.random.default_rng(71 if case == "threshold" else 72)
+    P, K, W = 16384, 16, 8
+    x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+    th = np.empty((W, K, 4))
+    th[:, :, 1] = rng.uniform(x[0], x[-1], (W, K))
+    if case == "threshold":
+        import os
+        wide_max = float(os.environ.get("VAMP_TEST_WIDE_MAX", "1.0"))        # VAMP_WIDE_MAX of the library under test
+        edge = 128.0 * 2.0 * np.sqrt(np.log(2.0)) / wide_max      # G at which half a tile is wide_max in z
+        th[:, :, 3] = edge * np.where(rng.random((W, K)) < 0.6, 1.0 + rng.uniform(0.0, 0.1, (W, K)), 1.0 - rng.uniform(0.0, 0.1, (W, K)))
+        th[:, :, 2] = 10.0 ** rng.uniform(-6, 2.5, (W, K))
+        th[:, :, 0] = 10.0 ** rng.uniform(-2, 0.7, (W, K))
+        th[:, 0, 0] = 50.0                                        # one saturated wide line per walker
+    else:
+        fw = (x[-1] - x[0]) / 2.0 * 2.0 * np.sqrt(2.0 * np.log(2.0))
+        th[:, :, 3] = rng.uniform(0.0, fw, (W, K))
+        th[:, :, 2] = rng.uniform(0.0, fw, (W, K))
+        th[:, :, 0] = rng.gamma(2.0, 1.0, (W, K))
+    th = th.reshape(W, 4 * K)
+    noise = np.full(P, 0.05)
+    flux = np.clip(1.0 + rng.normal(0, 0.05, P), 0, None)
+    r = vo.Region(x=x, flux=flux, noise=noise, n_comp=K, mode=vo.MODE_VOIGT4)
+    hip_ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
+    want = vo.log_prob_batch_fast(r, th)
+    got = hip_ctx.lnprob(th)
+    assert np.isfinite(want).all() and np.isfinite(got).all()
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() <= 1e-9, (case, err)
+    tau, fl = hip_ctx.model(th[0])                                 # (k_model evaluates every pixel directly: the same answer)
+    assert np.allclose(fl, vo.model_flux(r, th[0]), rtol=1e-12, atol=1e-300)
+    hip_ctx.sampler_init(th, seed=9, split_block=W)
+    res = hip_ctx.run(1)
+    chain, lchain, nacc = vo.run_sampler(lambda q: vo.log_prob_batch_fast(r, q), th, want, 1, seed=9, block=W)
+    assert np.array_equal(res["n_accept"], nacc) and np.allclose(res["chain"], chain, rtol=1e-10, atol=1e-12), case
+    print("wide lines (%s): worst lnprob error %.2e" % (case, err.max()))
+
+
 @pytest.mark.parametrize("packing", [0, 64])
 def test_full_size_dispersed_walkers_fp32(packing):
     """The same non-converged walkers at the headline's full size through the fp32 path -- single-precision

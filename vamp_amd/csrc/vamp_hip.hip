@@ -78,8 +78,9 @@
 #define VAMP_WIDE_NODES 1      // lines far wider than a tile join the tile's interpolant (sweep_range_ff)
 #endif
 #ifndef VAMP_WIDE_MAX
-#define VAMP_WIDE_MAX 0.5      // ... when the tile's half-width is at most this many units of the line's z
-#endif
+#define VAMP_WIDE_MAX 1.0      // ... when the tile's half-width is at most this many units of the line's z.  Measured at the
+#endif                         // switch, worst lnprob error of saturated lines (profiles/r04_e_wide_lines.txt): 0.5: 5e-16,
+                               // 0.75: 6e-15, 1.0: 1.5e-12, 1.25: 5e-11 (the bar is 1e-9): 1.0 keeps three decades of margin
 #ifndef VAMP_F32_LEAN_STAGE
 #define VAMP_F32_LEAN_STAGE 1
 #endif
@@ -848,9 +849,9 @@ __device__ __forceinline__ void ff_coefficients(const LDS& L, TileScratch& Sx, c
 // An ensemble drawn from the priors (widths ~ U(0, fwhm_max): where every find_bic repeat STARTS, vpfits.py:283-297) has
 // nothing far: every line is wider than the region, every (line, tile) pair is near and costs four table look-ups per
 // lane (profiles/r03_c_headline_robustness.txt: 12.5 ms per swept half-step against 3.4).  But seen from a tile, such a
-// line is as smooth as a far one: w is entire, and over a tile whose half-width is at most VAMP_WIDE_MAX = 1/2 in the
-// line's own z the degree-15 interpolant through the tile's 16 Chebyshev nodes reproduces its optical depth to ~1e-14
-// (coefficients fall like (a/2)^n / sqrt(n!)).  So the roles of "far" and "wide" are exchanged: wide lines are evaluated
+// line is as smooth as a far one: w is entire, and over a tile whose half-width is at most VAMP_WIDE_MAX = 1 in the
+// line's own z (G_fwhm >~ 213 px on a unit grid) the degree-15 interpolant through the tile's 16 Chebyshev nodes
+// reproduces its optical depth to ~1e-12 (coefficients fall like (a/2)^n / sqrt(n!)).  So the roles of "far" and "wide" are exchanged: wide lines are evaluated
 // at the NODES -- (node, line) pairs over the lanes as for the far lines, 4 lines per lane, through the line's own
 // Taylor table (or the 6-level fraction beyond |z| = 8) -- and join the far lines' node sums before the one transform.
 // 16 wide lines: 4 look-ups per lane and tile instead of 64.
