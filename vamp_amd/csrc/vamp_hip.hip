@@ -78,9 +78,9 @@
 #define VAMP_WIDE_NODES 1      // lines far wider than a tile join the tile's interpolant (sweep_range_ff)
 #endif
 #ifndef VAMP_WIDE_MAX
-#define VAMP_WIDE_MAX 1.0      // ... when the tile's half-width is at most this many units of the line's z.  Measured at the
-#endif                         // switch, worst lnprob error of saturated lines (profiles/r04_e_wide_lines.txt): 0.5: 5e-16,
-                               // 0.75: 6e-15, 1.0: 1.5e-12, 1.25: 5e-11 (the bar is 1e-9): 1.0 keeps three decades of margin
+#define VAMP_WIDE_MAX 0.75     // ... when the tile's half-width is at most this many units of the line's z.  Worst relative lnprob
+#endif                         // error at the switch on well-fitted data at S/N 200 (tests/wide_probe.py, profiles/r04_e_wide_lines.txt):
+                               // 0.5: 4e-16, 0.75: 4e-14, 1.0: 1.2e-12 (3e-11 with amplitudes of 20), 1.25: 7e-11; the bar is 1e-9
 #ifndef VAMP_F32_LEAN_STAGE
 #define VAMP_F32_LEAN_STAGE 1
 #endif
@@ -244,7 +244,9 @@ using PackXL = Pack<64, KMAX_ALL, true, 2, false, false, false>;
 
 constexpr int FF_NODES = 16;          // Chebyshev nodes of the far-field interpolant of one tile
 #ifndef VAMP_FF_DIST
-#define VAMP_FF_DIST 4.0
+#define VAMP_FF_DIST 2.0        // (round 4: was 4.  The series reproduce a wing from 2 half-widths to 3e-11 of ITS value there,
+                                //  tests/test_ff_matrix.py; on well-fitted data with strong damped wings the log-posterior moves
+                                //  by 6e-15, tests/ff_probe.py; one tile fewer per side where a narrow line is near: -2.5 %)
 #endif
 constexpr double FF_DIST = VAMP_FF_DIST;   // a line is "far" from a tile when it lies >= FF_DIST half-widths beyond its edge
 #include "ff_matrix.inc"               // FF_M, FF_DEG, FF_ROWS, FF_MAT (tools/gen_ff_matrix.py)
@@ -695,15 +697,16 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const typename P
 // Seen from a tile of 256 consecutive pixels, a line whose centre lies >= FF_DIST half-widths
 // beyond the tile's edge contributes an optical depth that is analytic across the tile with its
 // nearest singularity (the line centre) that far away: a degree-15 Chebyshev interpolant
-// reproduces it to 4e-15 relative (singularity at (FF_DIST + 1) half-widths from the tile centre:
-// Bernstein ellipse parameter 5 + sqrt(24) = 9.9 for FF_DIST = 4, and 9.9^-16 = 1.2e-16).  Polynomials add, so ALL far lines of the tile share one interpolant:
+// reproduces it to 6e-13 relative (singularity at (FF_DIST + 1) half-widths from the tile centre:
+// Bernstein ellipse parameter 3 + sqrt(8) = 5.8 for FF_DIST = 2, and 5.8^-16 = 6e-13; FF_DIST = 4: 9.9^-16 = 1.2e-16).  Polynomials add, so ALL far lines of the tile share one interpolant:
 //   1. the (node, far line) pairs -- 16 nodes x up to 16 lines -- are spread over the 64 lanes
 //      (lane = 16 * (line slot) + node) and evaluated with the same Voigt code, 4 lines per pass;
 //   2. node values are summed over lines (two xor shuffles) and turned by ONE 56 x 16 matrix held in
 //      LDS (one row per lane, tools/gen_ff_matrix.py) into four local power series, one per quarter
 //      of the tile -- a lane holds one pixel of each quarter -- with 14 coefficients each: seen from
-//      a quarter's centre the far lines are >= 17 quarter half-widths away, the coefficients fall
-//      like 17^-j and the terms beyond u^13 are < 1e-17 of the value;
+//      a quarter's centre the far lines are >= 9 quarter half-widths away, the coefficients fall
+//      like 9^-j and the terms beyond u^13 are < 3e-11 of the value (of a wing that is itself a small part
+//      of the optical depth there);
 //   3. every pixel of the tile runs Horner's rule on its quarter's series: 13 fused multiply-adds
 //      (Clenshaw's recurrence on the tile's Chebyshev coefficients cost 30) instead of ~27
 //      instructions per far line.
@@ -849,9 +852,9 @@ __device__ __forceinline__ void ff_coefficients(const LDS& L, TileScratch& Sx, c
 // An ensemble drawn from the priors (widths ~ U(0, fwhm_max): where every find_bic repeat STARTS, vpfits.py:283-297) has
 // nothing far: every line is wider than the region, every (line, tile) pair is near and costs four table look-ups per
 // lane (profiles/r03_c_headline_robustness.txt: 12.5 ms per swept half-step against 3.4).  But seen from a tile, such a
-// line is as smooth as a far one: w is entire, and over a tile whose half-width is at most VAMP_WIDE_MAX = 1 in the
-// line's own z (G_fwhm >~ 213 px on a unit grid) the degree-15 interpolant through the tile's 16 Chebyshev nodes
-// reproduces its optical depth to ~1e-12 (coefficients fall like (a/2)^n / sqrt(n!)).  So the roles of "far" and "wide" are exchanged: wide lines are evaluated
+// line is as smooth as a far one: w is entire, and over a tile whose half-width is at most VAMP_WIDE_MAX = 3/4 in the
+// line's own z (G_fwhm >~ 284 px on a unit grid) the degree-15 interpolant through the tile's 16 Chebyshev nodes
+// reproduces its optical depth to ~5e-12 of its peak (the first dropped coefficient, 2 e^{-a^2/2} I_8(a^2/2)).  So the roles of "far" and "wide" are exchanged: wide lines are evaluated
 // at the NODES -- (node, line) pairs over the lanes as for the far lines, 4 lines per lane, through the line's own
 // Taylor table (or the 6-level fraction beyond |z| = 8) -- and join the far lines' node sums before the one transform.
 // 16 wide lines: 4 look-ups per lane and tile instead of 64.
