@@ -40,10 +40,18 @@ def classify(wl, n_walkers=64):
     lo, hi = x[0::256][:nt], x[255::256][:nt]
     mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
     dist = np.abs(mid[None, None, :] - c[:, :, None]) - half[None, None, :]            # [W, K, tiles]
-    far = (dist >= 4.0 * half[None, None, :]) & (dist >= w8[:, :, None])
-    near = ~far
+    # the library's rules (vamp_hip.hip: VAMP_FF_DIST 2, VAMP_WIDE_MAX 3/4, VAMP_MID_Z2 30.25): far = centre >= 2 half-widths beyond
+    # the edge and the tile outside |z| < 8; at the nodes through the table = wide (half a tile <= 3/4 z) or that far away and
+    # outside |z|^2 < 30.25; near = the rest, evaluated at every pixel
+    wmid = np.sqrt(np.maximum(30.25 - y * y, 0.0)) / s
+    away = dist >= 2.0 * half[None, None, :]
+    far = away & (dist >= w8[:, :, None])
+    wide = (s * half.max() <= 0.75)[:, :, None] & ~far
+    midz = away & (dist >= wmid[:, :, None]) & ~far
+    near = ~(far | wide | midz)
     in_zone = near & (dist + 2 * half[None, None, :] <= w8[:, :, None])                 # the whole tile inside |z| < 8
     nfar = far.sum(axis=1)                                                              # [W, tiles]
+    n_nodes = (wide | midz).sum(axis=(1, 2)).mean()
     # share of stretch proposals that land inside the priors (the others are rejected before the sweep: a walker
     # outside its prior costs the staging only): random pairs of this ensemble, z = ((a - 1) u + 1)^2 / a, a = 2
     rng = np.random.default_rng(5)
@@ -60,6 +68,7 @@ def classify(wl, n_walkers=64):
     return {"proposals_inside_prior": float(ok.mean()),
             "near_pairs_per_walker": float(near.sum(axis=(1, 2)).mean()),
             "near_pairs_wholly_in_table_zone": float(in_zone.sum(axis=(1, 2)).mean()),
+            "table_pairs_at_the_nodes": float(n_nodes),
             "tiles_with_more_than_8_far_lines": float((nfar > 8).mean()),
             "nfar_hist": np.bincount(nfar.ravel(), minlength=K + 1).tolist()}
 
@@ -110,7 +119,7 @@ def main():
         rows.append((ens, ws, j["value"], j["roofline"]["avg_launch_ms"], j["acceptance_fraction"], j["finite_lnprob_fraction"], cl))
         print(f"{ens:10s} widths x{ws:<5g} {j['value'] / 1e6:8.2f} M walker-steps/s  {j['roofline']['avg_launch_ms']:7.3f} ms/half-step  "
               f"accept {j['acceptance_fraction']:.3f}  proposals inside the prior {cl['proposals_inside_prior']:.2f} "
-              f"({j['roofline']['avg_launch_ms'] / max(cl['proposals_inside_prior'], 1e-9):6.3f} ms per half-step of swept proposals)  near pairs {cl['near_pairs_per_walker']:6.1f} "
+              f"({j['roofline']['avg_launch_ms'] / max(cl['proposals_inside_prior'], 1e-9):6.3f} ms per half-step of swept proposals)  near pairs {cl['near_pairs_per_walker']:6.1f} (+ {cl['table_pairs_at_the_nodes']:5.1f} at the nodes through the tables) "
               f"(in table zone {cl['near_pairs_wholly_in_table_zone']:6.1f})  tiles with > 8 far lines {cl['tiles_with_more_than_8_far_lines']:.2f}  "
               f"nfar hist {cl['nfar_hist']}"
               + ("" if busy is None else f"  VALU busy {busy:.2f}  VALU wave-instructions per launch {instr:.3e}"), flush=True)

@@ -77,6 +77,12 @@
 #ifndef VAMP_WIDE_NODES
 #define VAMP_WIDE_NODES 1      // lines far wider than a tile join the tile's interpolant (sweep_range_ff)
 #endif
+#ifndef VAMP_MID_NODES
+#define VAMP_MID_NODES 1       // lines >= FF_DIST half-widths beyond a tile whose |z| < 8 zone still reaches into it join the interpolant too ...
+#endif
+#ifndef VAMP_MID_Z2
+#define VAMP_MID_Z2 30.25      // ... when the whole tile is outside |z|^2 < this (e^{-30.25} = 7e-14 of the line's peak)
+#endif
 #ifndef VAMP_WIDE_MAX
 #define VAMP_WIDE_MAX 0.75     // ... when the tile's half-width is at most this many units of the line's z.  Worst relative lnprob
 #endif                         // error at the switch on well-fitted data at S/N 200 (tests/wide_probe.py, profiles/r04_e_wide_lines.txt):
@@ -142,6 +148,7 @@ struct LineRec {           // per (walker, component), lives in LDS
     double hy;             // core_hy(y)
     double xcap;           // +inf, or X_FAR when one tile of pixels spans > 16 units of |z| (narrow line)
     double w8, w25;        // half-widths, in x, of |z|^2 < 64 and |z|^2 < 625 around the centre (far-field classification)
+    double wmid;           // ... and of |z|^2 < VAMP_MID_Z2 (the Gaussian core's reach)
 };
 
 // Packing of walkers onto wavefronts.  LPW lanes serve one walker (SUBS = 64/LPW walkers share a
@@ -390,7 +397,7 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
         rec.c = c;
         if constexpr (MODE == VAMP_GAUSS3) {
             rec.s = 1.0 / sg; rec.y = 0.0; rec.amp = a; rec.pole = 0.0; rec.hy = 0.0; rec.xcap = __builtin_huge_val();
-            rec.w8 = rec.w25 = 0.0;
+            rec.w8 = rec.w25 = rec.wmid = 0.0;
         } else {
             const double rG = vamp::rcp_nr(G);          // one reciprocal for both scales (G = 0 -> inf -> rejected below)
             rec.s = (2.0 * SQRT_LN2) * rG;
@@ -404,10 +411,11 @@ __device__ __forceinline__ double stage_lines(const RegionDev& R, typename PK::L
             if constexpr (PK::FF) {
                 rec.w8 = sqrt(fmax(vamp::R2_CORE - rec.y * rec.y, 0.0)) / rec.s;
                 rec.w25 = sqrt(fmax(vamp::R2_M3 - rec.y * rec.y, 0.0)) / rec.s;
+                rec.wmid = sqrt(fmax(VAMP_MID_Z2 - rec.y * rec.y, 0.0)) / rec.s;
                 // half of the region's widest tile is at most VAMP_WIDE_MAX in this line's z: smooth across every tile
                 my_wide = VAMP_WIDE_NODES && TAB && rec.s * (0.5 * R.tile_span) <= VAMP_WIDE_MAX;
             } else {
-                rec.w8 = rec.w25 = 0.0;
+                rec.w8 = rec.w25 = rec.wmid = 0.0;
             }
             // a degenerate width (G = 0 or non-finite scale) makes the reference's profile NaN, which
             // its sampler rejects; reject here, before the sweep
@@ -969,6 +977,13 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const typenam
         int nwide = 0;
         if constexpr (WIDE) {
             widemask = wide_all & ~farmask;
+            if constexpr (VAMP_MID_NODES) {
+                // between "far" and "near": the centre is FF_DIST half-widths away, the tile still inside |z| < 8 of the line
+                // (where the node values cannot be continued fractions) but outside its Gaussian core: as smooth as a far
+                // line, evaluated at the nodes through its Taylor table like a wide one
+                const double dist = fabs(mid - me.c) - half;
+                widemask |= __ballot(lane < K && dist >= FF_DIST * half && dist >= me.wmid) & ~farmask;
+            }
             nwide = __builtin_popcountll(widemask);
             if ((widemask >> lane) & 1ull) Sx.widelist[__builtin_popcountll(widemask & ((1ull << lane) - 1ull))] = lane;
         }
@@ -1327,7 +1342,7 @@ __device__ __forceinline__ void sweep_class(const RegionDev& R, const typename P
                 // lines far wider than a tile (stage_lines left their mask in the parameter block): none on a converged ensemble
                 const unsigned long long wide_all =
                     (unsigned long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(L.theta[4 * PK::KCAP + 2]) & 0xffff));
-                if (wide_all) sweep_range_ff<MODE, PK, TAB, true>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi, tab, wide_all);
+                if (VAMP_MID_NODES || wide_all) sweep_range_ff<MODE, PK, TAB, true>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi, tab, wide_all);
                 else sweep_range_ff<MODE, PK, TAB, false>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi, tab);
             } else {
                 sweep_range_ff<MODE, PK, TAB>(R, L, Sx, dct, x, f, wt, lane, base0, full, stride, chi, tab);
