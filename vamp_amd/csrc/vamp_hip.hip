@@ -77,6 +77,12 @@
 #ifndef VAMP_WIDE_NODES
 #define VAMP_WIDE_NODES 1      // lines far wider than a tile join the tile's interpolant (sweep_range_ff)
 #endif
+#ifndef VAMP_F32_FAR_CORE
+#define VAMP_F32_FAR_CORE 1    // fp32 far field: far = outside the Gaussian core (|z|^2 >= VAMP_MID_Z2) instead of outside |z| < 8
+#endif
+#ifndef VAMP_CORE_FASTPATH
+#define VAMP_CORE_FASTPATH 1   // tile_voigt: a wavefront wholly inside |z| < 8 of a line evaluates its pixels in straight-line code
+#endif
 #ifndef VAMP_MID_NODES
 #define VAMP_MID_NODES 1       // lines >= FF_DIST half-widths beyond a tile whose |z| < 8 zone still reaches into it join the interpolant too ...
 #endif
@@ -180,8 +186,10 @@ __device__ unsigned int g_stamp_n;
             if (n_ < 8192) { g_stamps[2 * n_] = (tag); g_stamps[2 * n_ + 1] = __builtin_amdgcn_s_memtime(); g_stamp_n = n_ + 1; } \
         }                                                                                        \
     } while (0)
+#define VAMP_STAMP_AFTER(tag, v) do { asm volatile("" :: "v"(v)); VAMP_STAMP(tag); } while (0)     // once `v` has arrived
 #else
 #define VAMP_STAMP(tag) do {} while (0)
+#define VAMP_STAMP_AFTER(tag, v) do {} while (0)
 #endif
 #ifndef VAMP_SPLIT_WAVES
 #define VAMP_SPLIT_WAVES 4
@@ -595,6 +603,23 @@ __device__ __forceinline__ void tile_voigt(const LineRec& ln, const double* dtab
     if (__any(lo < vamp::R2_M3)) {
         if (__any(lo < vamp::R2_M4)) {
             if (__any(lo < vamp::R2_CORE)) {
+#if VAMP_CORE_FASTPATH
+                // every pixel of the wavefront inside the zone (the usual case where a line is near): straight-line code,
+                // T independent chains with all their LDS reads in flight together.  Behind per-pixel branches (below:
+                // a wavefront that straddles |z| = 8) the T evaluations run one after the other, each waiting for its own
+                // reads -- what a latency-bound small ensemble spends most of its sweep on
+                double hi = r2[0];
+#pragma unroll
+                for (int t = 1; t < T; ++t) hi = fmax(hi, r2[t]);
+                if (!__any(!(hi < vamp::R2_CORE))) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        if constexpr (TAB) H[t] = table_eval(tab, X[t]);
+                        else H[t] = vamp::voigt_core(X[t], y, dtab, ln.pole, ln.hy);
+                    }
+                    return;          // (inside |z| < 8 no pixel is beyond xcap = X_FAR)
+                }
+#endif
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     if (r2[t] < vamp::R2_CORE) {
@@ -667,6 +692,7 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const typename P
         }
         __builtin_amdgcn_sched_barrier(0);
 #endif
+        VAMP_STAMP_AFTER(31, xi[0]);
         if constexpr (gauss) {
             for (int k = 0; k < K; ++k) {
                 const double c = L.line[k].c, s = L.line[k].s, a = L.line[k].amp;
@@ -687,6 +713,7 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const typename P
                 for (int t = 0; t < T; ++t) tau[t] = fma(ln.amp, H[t], tau[t]);
             }
         }
+        VAMP_STAMP_AFTER(32, tau[0]);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const double m = vamp::exp_taylor(-tau[t]);
@@ -698,6 +725,7 @@ __device__ __forceinline__ void sweep_range(const RegionDev& R, const typename P
             const bool live = (base + LPW * t + lane) < P;
             chi += live ? r * r : 0.0;
         }
+        VAMP_STAMP_AFTER(33, chi);
     }
 }
 
@@ -1260,7 +1288,9 @@ __device__ __forceinline__ void sweep_range_f32_ff(const RegionDev& R, const typ
         int kq = kk;
         asm volatile("" : "+v"(kq));
         const LineRec& me = L.line[kq];
-        const unsigned long long farmask = ff_classify<4 * (int)sizeof(float)>(Sx, K, lane, me.c, me.w8, me.w25, mid, half);
+        // (fp32: the node values are W4 regions I / II, valid from |x| + y = 5.5 -- no |z| >= 8 condition as for the fp64
+        //  fractions: a line is far once the tile is outside its Gaussian core, |z|^2 >= VAMP_MID_Z2)
+        const unsigned long long farmask = ff_classify<4 * (int)sizeof(float)>(Sx, K, lane, me.c, VAMP_F32_FAR_CORE ? me.wmid : me.w8, me.w25, mid, half);
         const int nfar = __builtin_popcountll(farmask);
         // (VAMP_SKIP_*: timing-only builds of tools/variants.py -- the phase split in profiles/)
 #ifndef VAMP_SKIP_NEAR
