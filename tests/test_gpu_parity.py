@@ -1014,6 +1014,44 @@ def test_lines_wider_than_a_tile_match_oracle(hip_ctx, case):
     print("wide lines (%s): worst lnprob error %.2e" % (case, err.max()))
 
 
+FAR_FIELD_CASES = {   # G_fwhm range [px], log10 L range, amplitudes up to (< 0: log-uniform up to 10^-v)
+    "headline-like": (20, 200, -3, 0, 3.0), "damped": (5, 120, 0, 2.0, 10.0), "narrow strong": (2, 40, -1, 1.5, 50.0),
+    "mixed": (1, 400, -4, 2.5, 20.0), "damped wings": (5, 30, 1.5, 2.5, -2.5)}
+
+
+@pytest.mark.parametrize("case", list(FAR_FIELD_CASES))
+def test_far_field_on_well_fitted_data(hip_ctx, case):
+    """Round 4 moved the far field's borders inward: far from 2 tile half-widths (was 4), lines between far and near
+    and lines far wider than a tile at the nodes through their Taylor tables.  Its error is relative to a line's
+    value at the tile, so it weighs most where |lnprob| is smallest: data that IS the model of 16 lines plus noise at
+    S/N 200, walkers 1e-4 around the truth (|lnprob| ~ P/2, headline size) -- lines of every width and damping, strong
+    damped wings (optical depth ~1 hundreds of pixels from the centre), narrow lines of amplitude 50.  Log-posterior
+    against the oracle: the bar is 1e-9; measured 2e-16 .. 1e-13 (profiles/r04_h_ff_dist.txt), asserted at 1e-11."""
+    if hip_ctx.packing_request in (16, 65):
+        pytest.skip("long regions: one walker per wavefront or workgroup")
+    g_lo, g_hi, l_lo, l_hi, a_hi = FAR_FIELD_CASES[case]
+    P, K, W, sd = 16384, 16, 8, 0.005
+    x = np.arange(P, dtype=np.float64) - (P - 1) / 2.0
+    rng = np.random.default_rng(11)
+    t = np.empty((K, 4))
+    t[:, 1] = rng.uniform(x[0], x[-1], K)
+    t[:, 3] = rng.uniform(g_lo, g_hi, K)
+    t[:, 2] = 10.0 ** rng.uniform(l_lo, l_hi, K)
+    t[:, 0] = rng.uniform(0.3, a_hi, K) if a_hi > 0 else 10.0 ** rng.uniform(0.0, -a_hi, K)
+    truth = t.reshape(-1)
+    noise = np.full(P, sd)
+    r0 = vo.Region(x=x, flux=np.ones(P), noise=noise, n_comp=K, mode=vo.MODE_VOIGT4)
+    flux = vo.model_flux(r0, truth) + rng.normal(0, sd, P)
+    r = vo.Region(x=x, flux=flux, noise=noise, n_comp=K, mode=vo.MODE_VOIGT4)
+    th = truth[None, :] * (1.0 + 1e-4 * rng.standard_normal((W, 4 * K)))
+    hip_ctx.set_regions(x, flux, noise, K, mode=vo.MODE_VOIGT4)
+    want = vo.log_prob_batch_fast(r, th)
+    got = hip_ctx.lnprob(th)
+    assert np.isfinite(want).all() and np.abs(want).max() < 2.0 * P
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() <= 1e-11, (case, err)
+
+
 @pytest.mark.parametrize("packing", [0, 64])
 def test_full_size_dispersed_walkers_fp32(packing):
     """The same non-converged walkers at the headline's full size through the fp32 path -- single-precision
