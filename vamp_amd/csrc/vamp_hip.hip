@@ -77,6 +77,14 @@
 #ifndef VAMP_WIDE_NODES
 #define VAMP_WIDE_NODES 1      // lines far wider than a tile join the tile's interpolant (sweep_range_ff)
 #endif
+#ifndef VAMP_FLUX_EXP_DROP
+#define VAMP_FLUX_EXP_DROP 2   // far-field sweep: exp(-tau) of the model flux by the degree-11 kernel (6e-15) instead of degree 13
+#endif
+#ifndef VAMP_FF_R2_M4
+#define VAMP_FF_R2_M4 100.0    // far-field node values: below this |z|^2 the 6-level fraction, ...
+#define VAMP_FF_R2_M3 300.0    // ... below this the 4-level, ...
+#define VAMP_FF_R2_M2 2000.0   // ... below this the 3-level, beyond it the 2-level one
+#endif
 #ifndef VAMP_F32_FAR_CORE
 #define VAMP_F32_FAR_CORE 1    // fp32 far field: far = outside the Gaussian core (|z|^2 >= VAMP_MID_Z2) instead of outside |z| < 8
 #endif
@@ -790,10 +798,14 @@ __device__ __forceinline__ void ff_eval2(const double (&Xin)[2], const double (&
         r2[t] = fma(X[t], X[t], y[t] * y[t]);
     }
     const double lo = fmin(r2[0], r2[1]), hi = fmax(Xin[0], Xin[1]), ymin = fmin(y[0], y[1]);
-    if (__any(lo < vamp::R2_M3)) {
-        if (__any(lo < vamp::R2_M4)) ff_frac2<6>(X, y, r2, H);
+    // the fractions' ranges for NODE values: 4e-13 / 2e-13 / 9e-13 of the value at the lower ends (the m-level fraction is
+    // the 2m-point Gauss-Hermite rule of w's integral; the pixel evaluator's own ranges, R2_M4 / M3 / M2 = 196 / 625 / 1e4,
+    // hold 2e-15) -- the series these values feed reproduce a wing to 3e-11 of its value
+    constexpr double N_M4 = VAMP_FF_R2_M4, N_M3 = VAMP_FF_R2_M3, N_M2 = VAMP_FF_R2_M2;
+    if (__any(lo < N_M3)) {
+        if (__any(lo < N_M4)) ff_frac2<6>(X, y, r2, H);
         else ff_frac2<4>(X, y, r2, H);
-    } else if (__any(lo < vamp::R2_M2)) {
+    } else if (__any(lo < N_M2)) {
         ff_frac2<3>(X, y, r2, H);
     } else {
         ff_frac2<2>(X, y, r2, H);               // valid (more than accurate) beyond 1e8 too, up to X_FAR
@@ -1070,7 +1082,7 @@ __device__ __forceinline__ void sweep_range_ff(const RegionDev& R, const typenam
 #ifdef VAMP_SKIP_EXP
             const double m = 1.0 - tau[t];
 #else
-            const double m = vamp::exp_taylor_tab(-tau[t], ec);
+            const double m = vamp::exp_taylor_tab<VAMP_FLUX_EXP_DROP>(-tau[t], ec);
 #endif
             const double r = (fi[t] - m) * wi[t];
             chi = fma(r, r, chi);
