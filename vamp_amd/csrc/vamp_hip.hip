@@ -77,6 +77,9 @@
 #ifndef VAMP_WIDE_NODES
 #define VAMP_WIDE_NODES 1      // lines far wider than a tile join the tile's interpolant (sweep_range_ff)
 #endif
+#ifndef VAMP_LPT
+#define VAMP_LPT 1             // small ensembles: the regions of a launch class in order of decreasing work
+#endif
 #ifndef VAMP_FLUX_EXP_DROP
 #define VAMP_FLUX_EXP_DROP 2   // far-field sweep: exp(-tau) of the model flux by the degree-11 kernel (6e-15) instead of degree 13
 #endif
@@ -3375,7 +3378,23 @@ int vamp_set_regions(vamp_ctx* c, int n_regions, const int64_t* pix_off, const d
                 cl.regions = pl.regions[k];
                 part.push_back(cl);
             }
+#if VAMP_LPT
+            // small ensembles: a launch is a few rounds of wavefronts, each a serial chain whose length grows with the region's
+            // lines x pixels; the longest chains go FIRST, so that none starts in the last round (regions are independent and the
+            // draws are keyed by region and walker: the order changes no result)
+            bool reordered = false;
+            if (which == 1 || VAMP_LPT == 2)
+                for (LaunchClass& cl : part) {
+                    std::vector<int> before = cl.regions;
+                    std::stable_sort(cl.regions.begin(), cl.regions.end(), [&](int a, int b) {
+                        return (long long)R[a].K * R[a].P > (long long)R[b].K * R[b].P;
+                    });
+                    reordered = reordered || before != cl.regions;
+                }
+            if (part.size() > 1 || reordered)
+#else
             if (part.size() > 1)
+#endif
                 for (LaunchClass& cl : part) {
                     HIP_TRY(hipMalloc(&cl.list_d, cl.regions.size() * sizeof(int)));
                     HIP_TRY(hipMemcpy(cl.list_d, cl.regions.data(), cl.regions.size() * sizeof(int), hipMemcpyHostToDevice));
